@@ -1,0 +1,54 @@
+/*
+ * rpt_oracle.h — C interface of the CPU oracle (test infrastructure; see rpt_oracle.c).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ */
+#ifndef RPT_ORACLE_H
+#define RPT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirrors the 15 kernel arguments of the reference (CLSetup.cpp:150-164). */
+typedef struct rpt_oracle_args {
+    const void *objects;      /* rpt_object[object_count]            arg 0 */
+    int32_t object_count;     /*                                      arg 1 */
+    const void *vertices;     /* float3 (16 B) []                     arg 2 */
+    const void *normals;      /* float3 (16 B) []                     arg 3 */
+    const void *uvs;          /* float2 []                            arg 4 */
+    const void *triangles;    /* u32[9 * T]                           arg 5 */
+    const void *octrees;      /* rpt_octree[]                         arg 6 */
+    const void *octreeTris;   /* i32[]                                arg 7 */
+    const void *textures;     /* u8[]                                 arg 8 */
+    uint64_t texture_bytes;   /* size of the pool (address guard)           */
+    float white_point[3];     /*                                      arg 9 */
+    float ambient;            /*                                      arg 10 */
+    int32_t width, height;    /*                                      arg 11, 12 */
+    int32_t interval;         /*                                      arg 13 */
+    void *out_pixels;         /* rpt_pixel[width*height] or NULL      arg 14 */
+    float *out_rgb;           /* float[3*width*height] tonemapped RGB before packing, or NULL */
+} rpt_oracle_args;
+
+/* Work counters (whole call, summed over threads); names follow SURVEY.md §8a. */
+typedef struct rpt_oracle_stats {
+    uint64_t shadow_rays, sphere_tests, cube_tests, octree_calls, root_aabb_hits,
+             inside_starts, inside_descent_steps, descent_steps, leaf_visits, tri_tests, pixels_hit;
+} rpt_oracle_stats;
+
+/* Render rows [row_begin,row_end) with `threads` host threads. stats may be NULL. 0 = ok. */
+int rpt_oracle_render(const rpt_oracle_args *a, int row_begin, int row_end, int threads,
+                      rpt_oracle_stats *stats);
+
+/* Per-function known-answer entry points. */
+int  rpt_oracle_tri(const float *A, const float *B, const float *C, const float *org, const float *dir, float *out3);
+int  rpt_oracle_aabb(const float *bmin, const float *bmax, const float *org, const float *dir, float *d2, int *sides2);
+void rpt_oracle_camray(float x, float y, int w, int h, float *dir3);
+void rpt_oracle_hable(const float *in3, float *out3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,162 @@
+"""ctypes bindings of the two in-tree shared libraries.
+
+* ``librpt_scene.so`` — host-only scene front-end (``include/rpt_scene.h``)
+* ``librpt_hip.so``   — the HIP render path for gfx950 (``include/rpt.h``)
+
+The libraries are looked up next to this file (they are built in-tree by
+``relativitypathtracer_amd/csrc/Makefile`` / ``__graft_entry__.build()``).  There is no CPU
+fallback for the render path: if ``librpt_hip.so`` is missing or fails to load, ``hip()`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Float2(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float)]
+
+
+class Float4(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("w", C.c_float)]
+
+
+class Object(C.Structure):
+    """rpt_object — 320 B (reference Object.h:6-22)."""
+    _fields_ = [
+        ("M", Float4 * 4), ("InvM", Float4 * 4), ("Lorentz", Float4 * 4), ("InvLorentz", Float4 * 4),
+        ("stationaryCam", Float4), ("color", Float4),
+        ("type", C.c_int32), ("meshIndex", C.c_int32), ("textureIndex", C.c_int32),
+        ("textureWidth", C.c_int32), ("textureHeight", C.c_int32),
+        ("light", C.c_uint8), ("_pad", C.c_uint8 * 3),
+        ("flashPeriod", C.c_float), ("flashDuration", C.c_float),
+    ]
+
+
+class Octree(C.Structure):
+    """rpt_octree — 96 B (reference Octree.h:4-12)."""
+    _fields_ = [
+        ("min", Float4), ("max", Float4), ("trisIndex", C.c_int32), ("trisCount", C.c_int32),
+        ("children", C.c_int32 * 8), ("neighbors", C.c_int32 * 6),
+    ]
+
+
+class SceneDesc(C.Structure):
+    """rpt_scene_desc — the eight scene arrays as {pointer, count} pairs."""
+    _fields_ = [
+        ("objects", C.c_void_p), ("object_count", C.c_size_t),
+        ("vertices", C.c_void_p), ("vertex_count", C.c_size_t),
+        ("normals", C.c_void_p), ("normal_count", C.c_size_t),
+        ("uvs", C.c_void_p), ("uv_count", C.c_size_t),
+        ("triangles", C.c_void_p), ("triangle_words", C.c_size_t),
+        ("octrees", C.c_void_p), ("octree_count", C.c_size_t),
+        ("octreeTris", C.c_void_p), ("octree_tri_count", C.c_size_t),
+        ("textures", C.c_void_p), ("texture_bytes", C.c_size_t),
+    ]
+
+
+assert C.sizeof(Object) == 320 and C.sizeof(Octree) == 96 and C.sizeof(SceneDesc) == 128
+
+TextureDecoder = C.CFUNCTYPE(C.c_int, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                             C.POINTER(C.c_int), C.c_void_p)
+
+_scene_lib = None
+_hip_lib = None
+
+
+def _path(name: str) -> str:
+    return os.path.join(_HERE, name)
+
+
+def scene_lib() -> C.CDLL:
+    global _scene_lib
+    if _scene_lib is None:
+        p = _path("librpt_scene.so")
+        if not os.path.exists(p):
+            raise RuntimeError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `make -C relativitypathtracer_amd/csrc`")
+        lib = C.CDLL(p)
+        P, I, S = C.c_void_p, C.c_int, C.c_char_p
+        FP = C.POINTER(C.c_float)
+        sig = {
+            "rpt_scene_create": (P, []),
+            "rpt_scene_destroy": (None, [P]),
+            "rpt_scene_last_error": (S, [P]),
+            "rpt_scene_set_asset_root": (I, [P, S]),
+            "rpt_scene_add_alias": (I, [P, S, S]),
+            "rpt_scene_set_texture_decoder": (I, [P, TextureDecoder, P]),
+            "rpt_scene_input": (I, [P, S]),
+            "rpt_scene_read_obj": (I, [P, S]),
+            "rpt_scene_read_texture": (I, [P, S]),
+            "rpt_scene_add_texture_rgb8": (I, [P, P, I, I]),
+            "rpt_scene_set_camera": (I, [P, FP, FP]),
+            "rpt_scene_get_camera": (I, [P, FP, FP]),
+            "rpt_scene_accelerate": (I, [P, FP, I]),
+            "rpt_scene_reset_velocity": (I, [P]),
+            "rpt_scene_set_paused": (I, [P, I]),
+            "rpt_scene_advance_time": (I, [P, I]),
+            "rpt_scene_set_interval": (I, [P, I]),
+            "rpt_scene_toggle_interval": (I, [P]),
+            "rpt_scene_update_objects": (I, [P]),
+            "rpt_scene_get_desc": (I, [P, C.POINTER(SceneDesc)]),
+            "rpt_scene_get_params": (I, [P, FP, FP, C.POINTER(C.c_int)]),
+            "rpt_scene_get_velocities": (I, [P, C.POINTER(P), C.POINTER(C.c_size_t)]),
+            "rpt_scene_get_mesh_roots": (I, [P, C.POINTER(P), C.POINTER(C.c_size_t)]),
+            "rpt_write_ppm": (I, [S, P, I, I]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _scene_lib = lib
+    return _scene_lib
+
+
+HIP_SYMBOLS = {
+    # name: (restype, argtypes) — exactly the entry points include/rpt.h declares
+    "rpt_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "rpt_destroy": (None, [C.c_void_p]),
+    "rpt_last_error": (C.c_char_p, [C.c_void_p]),
+    "rpt_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
+    "rpt_set_objects": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "rpt_set_params": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.c_int, C.c_int, C.c_int]),
+    "rpt_set_output": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rpt_set_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "rpt_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rpt_set_debug_rgb": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rpt_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
+    "rpt_render": (C.c_int, [C.c_void_p]),
+    "rpt_render_async": (C.c_int, [C.c_void_p]),
+    "rpt_sync": (C.c_int, [C.c_void_p]),
+    "rpt_output_ptr": (C.c_void_p, [C.c_void_p]),
+    "rpt_output_bytes": (C.c_size_t, [C.c_void_p]),
+    "rpt_read_framebuffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rpt_read_debug_rgb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rpt_last_frame_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "rpt_timed_frames": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    "rpt_scatter_colour_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rpt_colour_plane_ptr": (C.c_void_p, [C.c_void_p]),
+    "rpt_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "rpt_version": (C.c_char_p, []),
+}
+
+
+def hip_lib_path() -> str:
+    return _path("librpt_hip.so")
+
+
+def hip() -> C.CDLL:
+    """Load librpt_hip.so (the product render path).  Raises if it is missing — there is no fallback."""
+    global _hip_lib
+    if _hip_lib is None:
+        p = hip_lib_path()
+        if not os.path.exists(p):
+            raise RuntimeError(f"{p} is missing: the HIP render path has no CPU fallback; build it with "
+                               "`python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(p)
+        for name, (res, args) in HIP_SYMBOLS.items():
+            fn = getattr(lib, name)   # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        _hip_lib = lib
+    return _hip_lib
