@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the render path on MI355X.
+
+Metric (BASELINE.json): Mrays/s (primary rays per second = W*H/frame time/1e6) and ms/frame on
+Scenes/bunny.txt at 3840x2160, on N GPUs of one node.
+
+A "step" is one frame: refresh Object[] on the device (rpt_set_objects, as the reference's render()
+does every frame, Render.cpp:202) + render every pixel; with N > 1 each rank renders its interleaved
+8-row tiles into a 4 B/pixel colour plane, ONE RCCL gather over xGMI brings the planes to rank 0,
+and a root-side kernel expands them into the 16 B/pixel framebuffer.  Scene buffers are resident in
+HBM before the timed region; the framebuffer stays in device memory (the reference never reads back).
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see the keys at the bottom of main()).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md): the contract roofline for this path
+
+WORKLOADS = {
+    # name: (scene file, camera velocity, camera time)   — BASELINE.md §3
+    "bunny": ("bunny", (0.0, 0.0, 0.0), 0.0),
+    "shadows": ("shadows", (0.0, 0.0, 0.0), 16.0),
+    "arch": ("arch", (0.0, 0.0, 0.95), 5.25),
+    "cube": ("cube", (0.0, 0.0, 0.0), 0.0),
+}
+
+
+def algorithmic_bytes(width, height, n_objects):
+    """compulsory bytes of one frame = 16 B/pixel written + Object[] re-read.
+
+    First-touch scene bytes are excluded: they are resident (L2 / Infinity Cache) across frames."""
+    return 16 * width * height + 320 * n_objects
+
+
+def cpu_baseline(scene, width, height, budget_s=12.0):
+    """Time the oracle (the CPU restatement of the reference path) on this host: whole frames of
+    the SAME workload, repeated until ~budget_s of wall time, all hardware threads, plus one
+    single-thread frame.  Reported next to the GPU number; it is not the target."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi
+    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    oracle_ffi.render(scene, width, min(height, 64), want_rgb=False, threads=threads)   # page in
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        oracle_ffi.render(scene, width, height, want_rgb=False, threads=threads)
+        frames += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s * 0.7 or frames >= 64:
+            break
+    mt = width * height * frames / el / 1e6
+    # single thread on a quarter-height horizontal band through the middle of the frame (the costly rows)
+    band = (height * 3 // 8, height * 5 // 8)
+    t1 = time.perf_counter()
+    oracle_ffi.render(scene, width, height, rows=band, want_rgb=False, threads=1)
+    st = width * (band[1] - band[0]) / (time.perf_counter() - t1) / 1e6
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except Exception:
+        pass
+    return {
+        "value": round(mt, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": f"{frames} whole frame(s) of the same workload ({width}x{height}), {el:.1f} s wall, {threads} threads; "
+                  f"1-thread figure on the middle quarter band: {st:.3f} Mrays/s",
+        "ms_per_frame": round(el / frames * 1e3, 2), "single_thread_mrays": round(st, 3), "cpu": cpu_model,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="bunny", choices=sorted(WORKLOADS))
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", default="plane4", choices=["plane4"], help="what is gathered with N>1 (4 B/pixel colour plane)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from relativitypathtracer_amd import Scene
+    from relativitypathtracer_amd.renderer import Renderer, TILE_ROWS
+    from relativitypathtracer_amd import dist as rdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n = args.gpus
+    if world != n:
+        if world == 1 and n > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        n = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if n > 1:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H = args.width, args.height
+    scene_name, vel, t = WORLDS = WORKLOADS[args.workload]
+    scene = Scene.from_file(scene_name)
+    scene.set_camera(vel, t)
+    scene.update_objects()
+    n_objects = scene.desc().object_count
+
+    r = Renderer(local_rank)
+    stream = torch.cuda.current_stream()
+    r.set_stream(stream.cuda_stream)
+    r.upload_scene(scene)
+    r.set_scene_params(scene, W, H)
+    r.set_variant(args.variant)
+    frame = rdist.FrameSharder(r, W, H, rank, n)   # allocates outputs; N == 1 renders straight into the framebuffer
+
+    def step():
+        r.set_objects(scene)            # per-frame Object[] refresh, as the reference does
+        frame.render_and_gather()       # kernel (+ RCCL gather + root scatter when N > 1)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if n > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 0)):
+        step()
+    barrier()
+    r._check(r._lib.rpt_timing_begin(r._h, args.steps), "rpt_timing_begin")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    import ctypes as C
+    tot, nfr = C.c_float(), C.c_int()
+    r._check(r._lib.rpt_timing_end(r._h, C.byref(tot), C.byref(nfr)), "rpt_timing_end")
+    kernel_ms = tot.value / max(nfr.value, 1)     # average render-kernel duration on this rank, HIP events
+
+    if n > 1:
+        tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        elapsed, kernel_ms_max = float(tt[0]), float(tt[1])
+    else:
+        kernel_ms_max = kernel_ms
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        mrays = W * H / (ms_per_step * 1e-3) / 1e6
+        # roofline of the dominant kernel (the render kernel): algorithmic bytes one launch moves on this
+        # rank / its mean duration.  With N ranks one launch covers 1/N of the pixels (4 B/px plane).
+        if n == 1:
+            alg = algorithmic_bytes(W, H, n_objects)
+        else:
+            alg = 4 * W * frame.local_rows + 320 * n_objects
+        achieved = alg / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/s (primary rays) on Scenes/bunny.txt at 3840x2160" if (args.workload, W, H) == ("bunny", 3840, 2160)
+                      else f"Mrays/s (primary rays) on Scenes/{scene_name}.txt at {W}x{H}",
+            "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Scenes/{scene_name}.txt {W}x{H}, camera v={list(vel)} t={t}, interval={scene.params['interval']}, "
+                                   f"mesh=Models/bunny.obj (StanfordBunny.obj is missing from the reference)" if scene_name == "bunny"
+                       else f"Scenes/{scene_name}.txt {W}x{H}, camera v={list(vel)} t={t}",
+                       "frame": "rpt_set_objects + render kernel" + (" + RCCL gather(4 B/px plane) + root scatter" if n > 1 else ""),
+                       "sharding": "interleaved 8-row tiles, tile k -> rank k mod N" if n > 1 else "none",
+                       "variant": args.variant},
+            "kernel_ms": round(kernel_ms, 4),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "rpt_render_kernel", "algorithmic_bytes_per_launch": alg,
+                         "note": "16 B/pixel written + 320 B/object read per launch (SURVEY.md §8d); the path is "
+                                 "latency/VALU-bound by construction, HBM fraction reported because it is the contract"},
+        }
+        if not args.no_cpu_baseline and n == 1:
+            out["cpu_baseline"] = cpu_baseline(scene, W, H)
+        print(json.dumps(out), flush=True)
+    if n > 1:
+        td.barrier()
+        td.destroy_process_group()
+    r.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+/*
+ * rpt.h — C-ABI of librpt_hip.so: the per-pixel render path of the Relativity Path Tracer as
+ * hand-written HIP for MI355X (gfx950).
+ *
+ * The reference has no plugin/FFI interface for this path; its boundary is the sequence of OpenCL
+ * calls its C++ host makes.  Each entry point below replaces one of those call sites (file:line
+ * under the reference root), keeps the reference's buffer layouts (rpt_layout.h) and its
+ * conventions: the host owns every source array and the library copies (the reference uses
+ * blocking writes everywhere); calls are externally blocking unless named *_async; one host thread
+ * per context; every call returns 0 on success / nonzero on failure and never throws or aborts
+ * across the boundary (the reference ignores every cl_int; here they are reported).
+ *
+ *   rpt_create / rpt_destroy   initOpenCL()                        CLSetup.cpp:64-135
+ *   rpt_upload_scene           8x cl::Buffer + enqueueWriteBuffer   main.cpp:33-55
+ *   rpt_set_objects            per-frame write of Object[] + setArg(0)   Render.cpp:202-203
+ *   rpt_set_params             initCLKernel() setArg 1,9..13; resize/interval re-binds
+ *                                                                   CLSetup.cpp:150-163, Render.cpp:116-117,141
+ *   rpt_set_output             cl::BufferGL(vbo) + setArg(14)       main.cpp:58, Render.cpp:114-118
+ *   rpt_render                 runKernel()                          CLSetup.cpp:167-191
+ *
+ * Not in the reference (it never reads back, has one device and no timing): rpt_read_framebuffer,
+ * rpt_last_frame_ms, rpt_timed_frames, the *_async/stream calls, rpt_set_rows (pixel-row tiles for
+ * multi-GPU sharding) and rpt_scatter_colour_plane (root-side reassembly after the RCCL gather).
+ *
+ * There is no CPU or OpenCL fallback: without a gfx950 device rpt_create fails.
+ */
+#ifndef RPT_H
+#define RPT_H
+
+#include "rpt_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rpt_ctx rpt_ctx;
+
+enum rpt_status {
+    RPT_OK = 0,
+    RPT_ERR_ARG = 1,        /* null / out-of-range argument */
+    RPT_ERR_STATE = 2,      /* call made before the state it needs was set */
+    RPT_ERR_SCENE = 3,      /* scene buffers fail validation (an index points outside its array) */
+    RPT_ERR_DEVICE = 4,     /* HIP runtime error; see rpt_last_error */
+    RPT_ERR_NOMEM = 5
+};
+
+#define RPT_TILE_ROWS 8     /* height of one pixel-row tile (the sharding unit of rpt_set_rows) */
+
+const char *rpt_version(void);
+
+/* Create a context on HIP device `device_ordinal` (replaces platform/device pick, context+queue
+ * creation and the run-time program build: the gfx950 code object is prebuilt). */
+int rpt_create(rpt_ctx **out, int device_ordinal);
+void rpt_destroy(rpt_ctx *ctx);
+const char *rpt_last_error(const rpt_ctx *ctx);
+
+/* Upload the eight read-only scene arrays (copied; validated so that no index can leave its
+ * array).  The Object[] in `scene` is taken as the first rpt_set_objects. */
+int rpt_upload_scene(rpt_ctx *ctx, const rpt_scene_desc *scene);
+
+/* Refresh Object[] (count * 320 B, copied).  Called every frame by the reference's render(). */
+int rpt_set_objects(rpt_ctx *ctx, const void *objects, int count);
+
+/* Scalars: white_point (3 floats), ambient, width, height, interval (-1 or 0). */
+int rpt_set_params(rpt_ctx *ctx, const float white_point[3], float ambient, int width, int height, int interval);
+
+/* Output framebuffer: a device pointer to at least width*height*16 B (e.g. an interop buffer), or
+ * NULL for a library-owned buffer (headless). */
+int rpt_set_output(rpt_ctx *ctx, void *device_ptr_or_null);
+
+/* Pixel-row tiles rendered by this context: tiles first_tile, first_tile+tile_step, ... of
+ * RPT_TILE_ROWS rows each (default 0,1 = the whole frame).  With colour_plane != 0 the context
+ * renders into a compact library-owned plane of 4 B/pixel (the packed R,G,B,1 word only), its
+ * k-th local tile holding global tile first_tile + k*tile_step: the unit that is gathered. */
+int rpt_set_rows(rpt_ctx *ctx, int first_tile, int tile_step, int colour_plane);
+
+/* Launch on this HIP stream (hipStream_t as void*; NULL = the context's own stream). */
+int rpt_set_stream(rpt_ctx *ctx, void *hip_stream);
+
+/* Test hook: also write the tonemapped float RGB before 8-bit packing (3 floats/pixel, row-major,
+ * width*height*12 B) to this device pointer; NULL disables. 1 = library-owned buffer. */
+int rpt_set_debug_rgb(rpt_ctx *ctx, void *device_ptr_or_null_or_1);
+
+/* Kernel variant: 0 = default (fastest validated), others select alternative implementations of
+ * the same path for A/B measurement; all produce identical results. */
+int rpt_set_variant(rpt_ctx *ctx, int variant);
+
+/* Render one frame and wait for it (the reference's runKernel + finish). */
+int rpt_render(rpt_ctx *ctx);
+/* Enqueue one frame on the context's stream without waiting; rpt_sync waits. */
+int rpt_render_async(rpt_ctx *ctx);
+int rpt_sync(rpt_ctx *ctx);
+
+void *rpt_output_ptr(rpt_ctx *ctx);          /* device pointer of the current framebuffer */
+size_t rpt_output_bytes(rpt_ctx *ctx);
+void *rpt_colour_plane_ptr(rpt_ctx *ctx);    /* device pointer of the compact plane (rpt_set_rows) */
+/* Render the compact colour plane into caller-owned device memory (at least
+ * local_tiles*RPT_TILE_ROWS*width*4 B), e.g. the send buffer of the gather; NULL = library-owned. */
+int rpt_set_plane_output(rpt_ctx *ctx, void *device_ptr_or_null);
+
+int rpt_read_framebuffer(rpt_ctx *ctx, void *host_dst, size_t bytes);
+int rpt_read_debug_rgb(rpt_ctx *ctx, void *host_dst, size_t bytes);
+int rpt_last_frame_ms(rpt_ctx *ctx, float *ms);     /* device time of the last rendered frame */
+/* Render `frames` frames back to back and report the average device time per frame, measured
+ * with HIP events on the launch stream. */
+int rpt_timed_frames(rpt_ctx *ctx, int frames, float *avg_ms);
+
+/* Per-frame device timing over a region: after rpt_timing_begin every rpt_render[_async] brackets
+ * its kernel with its own pair of HIP events on the launch stream (up to `max_frames`);
+ * rpt_timing_end waits for them and returns the summed kernel time and the frame count. */
+int rpt_timing_begin(rpt_ctx *ctx, int max_frames);
+int rpt_timing_end(rpt_ctx *ctx, float *total_ms, int *frames);
+
+/* Root side of the multi-GPU exchange: expand `n_ranks` gathered colour planes (rank r's plane at
+ * planes + r*plane_stride_bytes) into the 16 B/pixel framebuffer `out16` (x, y, packed colour). */
+int rpt_scatter_colour_plane(rpt_ctx *ctx, const void *planes, void *out16, int width, int height,
+                             int n_ranks, int plane_stride_words, int reserved);
+
+/* Known-answer probes of individual device functions (tests): which = 0 intersect_triangle
+ * (in 15 floats -> out 4), 1 intersect_AABB (12 -> 5), 2 createCamRay (4 -> 3), 3 hable (3 -> 3). */
+int rpt_probe(rpt_ctx *ctx, int which, const void *host_in, void *host_out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPT_H */

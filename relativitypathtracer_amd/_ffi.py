@@ -137,6 +137,9 @@ HIP_SYMBOLS = {
     "rpt_timed_frames": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "rpt_scatter_colour_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rpt_colour_plane_ptr": (C.c_void_p, [C.c_void_p]),
+    "rpt_set_plane_output": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rpt_timing_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "rpt_timing_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "rpt_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "rpt_version": (C.c_char_p, []),
 }

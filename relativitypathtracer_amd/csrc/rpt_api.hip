@@ -1,0 +1,515 @@
+// rpt_api.hip — C-ABI of librpt_hip.so (include/rpt.h): context, scene upload with validation,
+// per-frame Object[] refresh, launch and read-back.  Host glue only; the device code is in
+// rpt_kernels.hip.h.  Replaces the reference's CLSetup.cpp / main.cpp:33-59 enqueue sequence.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rpt.h"
+#include "rpt_kernels.hip.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;      // bytes in use
+    size_t capacity = 0;
+};
+
+}  // namespace
+
+struct rpt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::string error;
+
+    DeviceBuffer objects, vertices, normals, uvs, triangles, octrees, octreeTris, textures;
+    DeviceBuffer owned_out, owned_plane, owned_rgb;
+    void *pinned_objects = nullptr;
+    size_t pinned_capacity = 0;
+    int object_count = 0;
+    size_t vertex_count = 0, normal_count = 0, uv_count = 0, triangle_words = 0, octree_count = 0, octree_tri_count = 0;
+    bool scene_uploaded = false;
+
+    float white_point[3] = {1, 1, 1};
+    float ambient = 1.0f;
+    int width = 0, height = 0, interval = -1;
+    bool params_set = false;
+
+    void *external_out = nullptr;
+    void *external_plane = nullptr;
+    void *external_rgb = nullptr;
+    std::vector<hipEvent_t> timing_events;   // pairs: begin,end per frame
+    int timing_frames = -1;                  // -1 = timing region not active
+    bool want_owned_rgb = false;
+    int first_tile = 0, tile_step = 1;
+    bool colour_plane = false;
+    int variant = 0;
+    float last_ms = 0.0f;
+    bool frame_rendered = false;
+};
+
+namespace {
+
+int fail(rpt_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->error = msg;
+    return code;
+}
+
+#define RPT_HIP(ctx, call)                                                                           \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(ctx, RPT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+int reserve(rpt_ctx *ctx, DeviceBuffer &b, size_t bytes) {
+    if (bytes > b.capacity) {
+        if (b.ptr) RPT_HIP(ctx, hipFree(b.ptr));
+        b.ptr = nullptr;
+        b.capacity = 0;
+        // at least 16 B so that an empty array still has a valid (never dereferenced) pointer
+        const size_t cap = bytes < 16 ? 16 : bytes;
+        RPT_HIP(ctx, hipMalloc(&b.ptr, cap));
+        b.capacity = cap;
+    }
+    b.bytes = bytes;
+    return RPT_OK;
+}
+
+int upload(rpt_ctx *ctx, DeviceBuffer &b, const void *src, size_t bytes) {
+    if (int rc = reserve(ctx, b, bytes)) return rc;
+    if (bytes) RPT_HIP(ctx, hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice));
+    return RPT_OK;
+}
+
+void release(DeviceBuffer &b) {
+    if (b.ptr) (void)hipFree(b.ptr);
+    b = DeviceBuffer();
+}
+
+// opencl_kernel.cl:607-616 on the host (same fp32 expression; this file is built without contraction)
+float hable_host(float x) {
+    const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+    return ((x * (A * x + C * B) + D * E) / (x * (A * x + B) + D * F)) - E / F;
+}
+
+// Every index the kernel will follow must stay inside its array: a GPU fault can reset the node.
+int validate_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
+    if (s.triangle_words % RPT_TRI_STRIDE) return fail(ctx, RPT_ERR_SCENE, "triangles: word count is not a multiple of 9");
+    const size_t n_tris = s.triangle_words / RPT_TRI_STRIDE;
+    for (size_t t = 0; t < n_tris; t++)
+        for (int k = 0; k < 3; k++) {
+            const uint32_t *w = s.triangles + 9 * t + 3 * k;
+            if (w[0] >= s.vertex_count) return fail(ctx, RPT_ERR_SCENE, "triangles: vertex index out of range");
+            if (w[1] >= s.uv_count) return fail(ctx, RPT_ERR_SCENE, "triangles: uv index out of range (pad uvs to >= 1 entry for vt-less meshes)");
+            if (w[2] >= s.normal_count) return fail(ctx, RPT_ERR_SCENE, "triangles: normal index out of range");
+        }
+    for (size_t i = 0; i < s.octree_tri_count; i++)
+        if (s.octreeTris[i] < 0 || (size_t)s.octreeTris[i] >= n_tris) return fail(ctx, RPT_ERR_SCENE, "octreeTris: triangle index out of range");
+    const long long n_nodes = (long long)s.octree_count;
+    for (size_t i = 0; i < s.octree_count; i++) {
+        const rpt_octree &n = s.octrees[i];
+        if (n.trisCount < 0 || n.trisIndex < 0 || (size_t)n.trisIndex + (size_t)n.trisCount > s.octree_tri_count)
+            return fail(ctx, RPT_ERR_SCENE, "octree: triangle range out of bounds");
+        for (int c = 0; c < 8; c++) {
+            if (n.children[c] < -1 || n.children[c] >= n_nodes) return fail(ctx, RPT_ERR_SCENE, "octree: child index out of range");
+            if (n.children[0] != -1 && (n.children[c] <= (long long)i)) return fail(ctx, RPT_ERR_SCENE, "octree: child index does not increase (descent would not terminate)");
+        }
+        for (int c = 0; c < 6; c++)
+            if (n.neighbors[c] < -1 || n.neighbors[c] >= n_nodes) return fail(ctx, RPT_ERR_SCENE, "octree: neighbour index out of range");
+    }
+    return RPT_OK;
+}
+
+int validate_objects(rpt_ctx *ctx, const rpt_object *objs, int count) {
+    for (int i = 0; i < count; i++) {
+        const rpt_object &o = objs[i];
+        if (o.type < RPT_SPHERE || o.type > RPT_MESH) return fail(ctx, RPT_ERR_SCENE, "object: unknown type");
+        if (o.type == RPT_MESH && (o.meshIndex < 0 || (size_t)o.meshIndex >= ctx->octree_count))
+            return fail(ctx, RPT_ERR_SCENE, "object: meshIndex is not an octree node");
+        if (o.textureIndex != -1) {
+            if (o.textureIndex < 0 || o.textureWidth <= 0 || o.textureHeight <= 0 ||
+                (unsigned long long)o.textureIndex + 3ull * (unsigned long long)o.textureWidth * (unsigned long long)o.textureHeight > ctx->textures.bytes)
+                return fail(ctx, RPT_ERR_SCENE, "object: texture lies outside the texture pool");
+        }
+    }
+    return RPT_OK;
+}
+
+int ensure_outputs(rpt_ctx *ctx) {
+    const size_t px = (size_t)ctx->width * ctx->height;
+    if (ctx->colour_plane) {
+        const int tiles = (ctx->height + RPT_TILE_ROWS - 1) / RPT_TILE_ROWS;
+        const int local_tiles = ctx->first_tile >= tiles ? 0 : (tiles - ctx->first_tile + ctx->tile_step - 1) / ctx->tile_step;
+        if (!ctx->external_plane)
+            if (int rc = reserve(ctx, ctx->owned_plane, (size_t)local_tiles * RPT_TILE_ROWS * ctx->width * 4)) return rc;
+    } else if (!ctx->external_out) {
+        if (px * 16 > ctx->owned_out.capacity || ctx->owned_out.bytes != px * 16) {
+            if (int rc = reserve(ctx, ctx->owned_out, px * 16)) return rc;
+            RPT_HIP(ctx, hipMemsetAsync(ctx->owned_out.ptr, 0, px * 16, ctx->stream));
+        }
+    }
+    if (ctx->want_owned_rgb) {
+        if (int rc = reserve(ctx, ctx->owned_rgb, px * 12)) return rc;
+    }
+    return RPT_OK;
+}
+
+int local_tile_count(const rpt_ctx *ctx) {
+    const int tiles = (ctx->height + RPT_TILE_ROWS - 1) / RPT_TILE_ROWS;
+    if (ctx->first_tile >= tiles) return 0;
+    return (tiles - ctx->first_tile + ctx->tile_step - 1) / ctx->tile_step;
+}
+
+int launch(rpt_ctx *ctx) {
+    if (!ctx->scene_uploaded) return fail(ctx, RPT_ERR_STATE, "rpt_render before rpt_upload_scene");
+    if (!ctx->params_set) return fail(ctx, RPT_ERR_STATE, "rpt_render before rpt_set_params");
+    if (int rc = ensure_outputs(ctx)) return rc;
+
+    rptd::KernelArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.objects = (const rpt_object *)ctx->objects.ptr;
+    a.vertices = (const rpt_float3 *)ctx->vertices.ptr;
+    a.normals = (const rpt_float3 *)ctx->normals.ptr;
+    a.uvs = (const rpt_float2 *)ctx->uvs.ptr;
+    a.triangles = (const uint32_t *)ctx->triangles.ptr;
+    a.octrees = (const rpt_octree *)ctx->octrees.ptr;
+    a.octreeTris = (const int32_t *)ctx->octreeTris.ptr;
+    a.textures = (const uint8_t *)ctx->textures.ptr;
+    a.texture_bytes = (long long)ctx->textures.bytes;
+    a.out16 = ctx->colour_plane ? nullptr : (rpt_pixel *)(ctx->external_out ? ctx->external_out : ctx->owned_out.ptr);
+    a.plane = ctx->colour_plane ? (uint32_t *)(ctx->external_plane ? ctx->external_plane : ctx->owned_plane.ptr) : nullptr;
+    a.debug_rgb = (float *)(ctx->external_rgb ? ctx->external_rgb : (ctx->want_owned_rgb ? ctx->owned_rgb.ptr : nullptr));
+    for (int c = 0; c < 3; c++) a.hable_wp[c] = hable_host(ctx->white_point[c]);
+    a.ambient = ctx->ambient;
+    a.aspect = (float)ctx->width / (float)ctx->height;
+    a.object_count = ctx->object_count;
+    a.width = ctx->width;
+    a.height = ctx->height;
+    a.interval = ctx->interval;
+    a.first_tile = ctx->first_tile;
+    a.tile_step = ctx->tile_step;
+
+    const int tiles = local_tile_count(ctx);
+    if (tiles == 0) return RPT_OK;
+    const dim3 grid((ctx->width + 31) / 32, tiles);
+    hipLaunchKernelGGL(rptd::rpt_render_kernel, grid, dim3(256), 0, ctx->stream, a);
+    RPT_HIP(ctx, hipGetLastError());
+    return RPT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rpt_version(void) { return "rpt-hip 0.1 (gfx950)"; }
+
+int rpt_create(rpt_ctx **out, int device_ordinal) {
+    if (!out) return RPT_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RPT_ERR_DEVICE;
+    if (device_ordinal < 0 || device_ordinal >= n) return RPT_ERR_ARG;
+    rpt_ctx *ctx = new (std::nothrow) rpt_ctx();
+    if (!ctx) return RPT_ERR_NOMEM;
+    ctx->device = device_ordinal;
+    if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) {
+        rpt_destroy(ctx);
+        return RPT_ERR_DEVICE;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return RPT_OK;
+}
+
+void rpt_destroy(rpt_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    for (DeviceBuffer *b : {&ctx->objects, &ctx->vertices, &ctx->normals, &ctx->uvs, &ctx->triangles, &ctx->octrees,
+                            &ctx->octreeTris, &ctx->textures, &ctx->owned_out, &ctx->owned_plane, &ctx->owned_rgb})
+        release(*b);
+    if (ctx->pinned_objects) (void)hipHostFree(ctx->pinned_objects);
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    for (hipEvent_t e : ctx->timing_events) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char *rpt_last_error(const rpt_ctx *ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+int rpt_upload_scene(rpt_ctx *ctx, const rpt_scene_desc *s) {
+    if (!ctx || !s) return RPT_ERR_ARG;
+    if ((s->object_count && !s->objects) || (s->vertex_count && !s->vertices) || (s->normal_count && !s->normals) ||
+        (s->uv_count && !s->uvs) || (s->triangle_words && !s->triangles) || (s->octree_count && !s->octrees) ||
+        (s->octree_tri_count && !s->octreeTris) || (s->texture_bytes && !s->textures))
+        return fail(ctx, RPT_ERR_ARG, "rpt_upload_scene: null pointer with nonzero count");
+    if (s->object_count > (1u << 20)) return fail(ctx, RPT_ERR_ARG, "rpt_upload_scene: too many objects");
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = validate_geometry(ctx, *s)) return rc;
+    RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->scene_uploaded = false;
+    if (int rc = upload(ctx, ctx->vertices, s->vertices, s->vertex_count * sizeof(rpt_float3))) return rc;
+    if (int rc = upload(ctx, ctx->normals, s->normals, s->normal_count * sizeof(rpt_float3))) return rc;
+    if (int rc = upload(ctx, ctx->uvs, s->uvs, s->uv_count * sizeof(rpt_float2))) return rc;
+    if (int rc = upload(ctx, ctx->triangles, s->triangles, s->triangle_words * sizeof(uint32_t))) return rc;
+    if (int rc = upload(ctx, ctx->octrees, s->octrees, s->octree_count * sizeof(rpt_octree))) return rc;
+    if (int rc = upload(ctx, ctx->octreeTris, s->octreeTris, s->octree_tri_count * sizeof(int32_t))) return rc;
+    if (int rc = upload(ctx, ctx->textures, s->textures, s->texture_bytes)) return rc;
+    ctx->vertex_count = s->vertex_count;
+    ctx->normal_count = s->normal_count;
+    ctx->uv_count = s->uv_count;
+    ctx->triangle_words = s->triangle_words;
+    ctx->octree_count = s->octree_count;
+    ctx->octree_tri_count = s->octree_tri_count;
+    ctx->scene_uploaded = true;
+    const int rc = rpt_set_objects(ctx, s->objects, (int)s->object_count);
+    if (rc) ctx->scene_uploaded = false;
+    return rc;
+}
+
+int rpt_set_objects(rpt_ctx *ctx, const void *objects, int count) {
+    if (!ctx || count < 0 || (count && !objects)) return RPT_ERR_ARG;
+    if (!ctx->scene_uploaded) return fail(ctx, RPT_ERR_STATE, "rpt_set_objects before rpt_upload_scene");
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = validate_objects(ctx, (const rpt_object *)objects, count)) return rc;
+    const size_t bytes = (size_t)count * sizeof(rpt_object);
+    if (bytes > ctx->pinned_capacity) {
+        if (ctx->pinned_objects) RPT_HIP(ctx, hipHostFree(ctx->pinned_objects));
+        ctx->pinned_objects = nullptr;
+        ctx->pinned_capacity = 0;
+        const size_t cap = bytes < 4096 ? 4096 : bytes * 2;
+        RPT_HIP(ctx, hipHostMalloc(&ctx->pinned_objects, cap, hipHostMallocDefault));
+        ctx->pinned_capacity = cap;
+    }
+    if (bytes > ctx->objects.capacity) RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = reserve(ctx, ctx->objects, bytes)) return rc;
+    if (bytes) {
+        // the staging copy must not be overwritten while a previous frame's transfer is in flight
+        RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(ctx->pinned_objects, objects, bytes);
+        RPT_HIP(ctx, hipMemcpyAsync(ctx->objects.ptr, ctx->pinned_objects, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ctx->object_count = count;
+    return RPT_OK;
+}
+
+int rpt_set_params(rpt_ctx *ctx, const float white_point[3], float ambient, int width, int height, int interval) {
+    if (!ctx || !white_point) return RPT_ERR_ARG;
+    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 31) - 1) return fail(ctx, RPT_ERR_ARG, "rpt_set_params: bad resolution");
+    for (int c = 0; c < 3; c++) ctx->white_point[c] = white_point[c];
+    ctx->ambient = ambient;
+    ctx->width = width;
+    ctx->height = height;
+    ctx->interval = interval;
+    ctx->params_set = true;
+    return RPT_OK;
+}
+
+int rpt_set_output(rpt_ctx *ctx, void *device_ptr_or_null) {
+    if (!ctx) return RPT_ERR_ARG;
+    ctx->external_out = device_ptr_or_null;
+    return RPT_OK;
+}
+
+int rpt_set_rows(rpt_ctx *ctx, int first_tile, int tile_step, int colour_plane) {
+    if (!ctx || first_tile < 0 || tile_step < 1) return RPT_ERR_ARG;
+    ctx->first_tile = first_tile;
+    ctx->tile_step = tile_step;
+    ctx->colour_plane = colour_plane != 0;
+    return RPT_OK;
+}
+
+int rpt_set_stream(rpt_ctx *ctx, void *hip_stream) {
+    if (!ctx) return RPT_ERR_ARG;
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return RPT_OK;
+}
+
+int rpt_set_debug_rgb(rpt_ctx *ctx, void *p) {
+    if (!ctx) return RPT_ERR_ARG;
+    ctx->want_owned_rgb = (p == (void *)1);
+    ctx->external_rgb = ctx->want_owned_rgb ? nullptr : p;
+    return RPT_OK;
+}
+
+int rpt_set_variant(rpt_ctx *ctx, int variant) {
+    if (!ctx || variant < 0 || variant > 0) return RPT_ERR_ARG;
+    ctx->variant = variant;
+    return RPT_OK;
+}
+
+int rpt_render_async(rpt_ctx *ctx) {
+    if (!ctx) return RPT_ERR_ARG;
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    hipEvent_t eb = ctx->ev_begin, ee = ctx->ev_end;
+    const bool timed = ctx->timing_frames >= 0 && (size_t)(2 * ctx->timing_frames + 1) < ctx->timing_events.size();
+    if (timed) {
+        eb = ctx->timing_events[2 * ctx->timing_frames];
+        ee = ctx->timing_events[2 * ctx->timing_frames + 1];
+    }
+    RPT_HIP(ctx, hipEventRecord(eb, ctx->stream));
+    if (int rc = launch(ctx)) return rc;
+    RPT_HIP(ctx, hipEventRecord(ee, ctx->stream));
+    if (timed) ctx->timing_frames++;
+    else if (ctx->timing_frames >= 0) return fail(ctx, RPT_ERR_STATE, "timing region is full");
+    ctx->frame_rendered = true;
+    return RPT_OK;
+}
+
+int rpt_timing_begin(rpt_ctx *ctx, int max_frames) {
+    if (!ctx || max_frames <= 0 || max_frames > (1 << 20)) return RPT_ERR_ARG;
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    while (ctx->timing_events.size() < (size_t)(2 * max_frames)) {
+        hipEvent_t e = nullptr;
+        RPT_HIP(ctx, hipEventCreate(&e));
+        ctx->timing_events.push_back(e);
+    }
+    ctx->timing_frames = 0;
+    return RPT_OK;
+}
+
+int rpt_timing_end(rpt_ctx *ctx, float *total_ms, int *frames) {
+    if (!ctx || !total_ms || !frames) return RPT_ERR_ARG;
+    if (ctx->timing_frames < 0) return fail(ctx, RPT_ERR_STATE, "rpt_timing_end without rpt_timing_begin");
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    float sum = 0.0f;
+    for (int i = 0; i < ctx->timing_frames; i++) {
+        float ms = 0.0f;
+        RPT_HIP(ctx, hipEventSynchronize(ctx->timing_events[2 * i + 1]));
+        RPT_HIP(ctx, hipEventElapsedTime(&ms, ctx->timing_events[2 * i], ctx->timing_events[2 * i + 1]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *frames = ctx->timing_frames;
+    ctx->timing_frames = -1;
+    return RPT_OK;
+}
+
+int rpt_set_plane_output(rpt_ctx *ctx, void *device_ptr_or_null) {
+    if (!ctx) return RPT_ERR_ARG;
+    ctx->external_plane = device_ptr_or_null;
+    return RPT_OK;
+}
+
+int rpt_sync(rpt_ctx *ctx) {
+    if (!ctx) return RPT_ERR_ARG;
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RPT_OK;
+}
+
+int rpt_render(rpt_ctx *ctx) {
+    if (int rc = rpt_render_async(ctx)) return rc;
+    return rpt_sync(ctx);
+}
+
+void *rpt_output_ptr(rpt_ctx *ctx) {
+    if (!ctx) return nullptr;
+    return ctx->external_out ? ctx->external_out : ctx->owned_out.ptr;
+}
+
+size_t rpt_output_bytes(rpt_ctx *ctx) { return ctx ? (size_t)ctx->width * ctx->height * 16 : 0; }
+
+void *rpt_colour_plane_ptr(rpt_ctx *ctx) { return ctx ? (ctx->external_plane ? ctx->external_plane : ctx->owned_plane.ptr) : nullptr; }
+
+int rpt_read_framebuffer(rpt_ctx *ctx, void *host_dst, size_t bytes) {
+    if (!ctx || !host_dst) return RPT_ERR_ARG;
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    const void *src = ctx->colour_plane ? rpt_colour_plane_ptr(ctx) : rpt_output_ptr(ctx);
+    const size_t have = ctx->colour_plane ? (size_t)local_tile_count(ctx) * RPT_TILE_ROWS * ctx->width * 4 : rpt_output_bytes(ctx);
+    if (!src || !ctx->frame_rendered) return fail(ctx, RPT_ERR_STATE, "rpt_read_framebuffer: nothing rendered yet");
+    if (bytes > have) return fail(ctx, RPT_ERR_ARG, "rpt_read_framebuffer: more bytes requested than the framebuffer holds");
+    RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RPT_HIP(ctx, hipMemcpy(host_dst, src, bytes, hipMemcpyDeviceToHost));
+    return RPT_OK;
+}
+
+int rpt_read_debug_rgb(rpt_ctx *ctx, void *host_dst, size_t bytes) {
+    if (!ctx || !host_dst) return RPT_ERR_ARG;
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    const void *src = ctx->external_rgb ? ctx->external_rgb : (ctx->want_owned_rgb ? ctx->owned_rgb.ptr : nullptr);
+    if (!src || !ctx->frame_rendered) return fail(ctx, RPT_ERR_STATE, "rpt_read_debug_rgb: debug RGB is not enabled or nothing rendered");
+    if (bytes > (size_t)ctx->width * ctx->height * 12) return fail(ctx, RPT_ERR_ARG, "rpt_read_debug_rgb: too many bytes");
+    RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RPT_HIP(ctx, hipMemcpy(host_dst, src, bytes, hipMemcpyDeviceToHost));
+    return RPT_OK;
+}
+
+int rpt_last_frame_ms(rpt_ctx *ctx, float *ms) {
+    if (!ctx || !ms) return RPT_ERR_ARG;
+    if (!ctx->frame_rendered) return fail(ctx, RPT_ERR_STATE, "rpt_last_frame_ms: nothing rendered yet");
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    RPT_HIP(ctx, hipEventSynchronize(ctx->ev_end));
+    RPT_HIP(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev_begin, ctx->ev_end));
+    *ms = ctx->last_ms;
+    return RPT_OK;
+}
+
+int rpt_timed_frames(rpt_ctx *ctx, int frames, float *avg_ms) {
+    if (!ctx || frames <= 0 || !avg_ms) return RPT_ERR_ARG;
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = launch(ctx)) return rc;   // untimed: allocates outputs, warms caches
+    RPT_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
+    for (int i = 0; i < frames; i++)
+        if (int rc = launch(ctx)) return rc;
+    RPT_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+    RPT_HIP(ctx, hipEventSynchronize(ctx->ev_end));
+    float ms = 0;
+    RPT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+    ctx->frame_rendered = true;
+    ctx->last_ms = ms / frames;
+    *avg_ms = ctx->last_ms;
+    return RPT_OK;
+}
+
+int rpt_scatter_colour_plane(rpt_ctx *ctx, const void *planes, void *out16, int width, int height, int n_ranks,
+                             int plane_stride_words, int reserved) {
+    if (!ctx || !planes || !out16 || width <= 0 || height <= 0 || n_ranks <= 0 || plane_stride_words < 0) return RPT_ERR_ARG;
+    const int tiles = (height + RPT_TILE_ROWS - 1) / RPT_TILE_ROWS;
+    const long long need = (long long)((tiles + n_ranks - 1) / n_ranks) * RPT_TILE_ROWS * width;
+    if ((long long)plane_stride_words < need) return fail(ctx, RPT_ERR_ARG, "rpt_scatter_colour_plane: plane stride smaller than one rank's plane");
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    const dim3 grid((width + 255) / 256, height);
+    hipLaunchKernelGGL(rptd::rpt_scatter_plane_kernel, grid, dim3(256), 0, ctx->stream, (const uint32_t *)planes,
+                       (rpt_pixel *)out16, width, height, n_ranks, (size_t)plane_stride_words);
+    RPT_HIP(ctx, hipGetLastError());
+    return RPT_OK;
+}
+
+int rpt_probe(rpt_ctx *ctx, int which, const void *host_in, void *host_out, int n) {
+    static const int in_w[4] = {15, 12, 4, 3}, out_w[4] = {4, 5, 3, 3};
+    if (!ctx || which < 0 || which > 3 || !host_in || !host_out || n <= 0) return RPT_ERR_ARG;
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    float *d_in = nullptr, *d_out = nullptr;
+    RPT_HIP(ctx, hipMalloc((void **)&d_in, sizeof(float) * in_w[which] * n));
+    if (hipMalloc((void **)&d_out, sizeof(float) * out_w[which] * n) != hipSuccess) {
+        (void)hipFree(d_in);
+        return fail(ctx, RPT_ERR_NOMEM, "rpt_probe: hipMalloc");
+    }
+    int rc = RPT_OK;
+    if (hipMemcpy(d_in, host_in, sizeof(float) * in_w[which] * n, hipMemcpyHostToDevice) != hipSuccess) rc = RPT_ERR_DEVICE;
+    if (!rc) {
+        hipLaunchKernelGGL(rptd::rpt_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, which, d_in, d_out, n);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+            hipMemcpy(host_out, d_out, sizeof(float) * out_w[which] * n, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(ctx, RPT_ERR_DEVICE, "rpt_probe: device error");
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+}  // extern "C"

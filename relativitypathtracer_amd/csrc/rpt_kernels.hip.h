@@ -1,0 +1,545 @@
+// rpt_kernels.hip.h — the per-pixel render path for gfx950 (CDNA4, wave64).
+//
+// What is computed is the reference's render_kernel (opencl_kernel.cl:620-660) and everything it
+// calls; how it is computed is organised for MI355X:
+//   * one wavefront owns an 8x8 pixel tile (coherent rays, 8 full 128-B lines per store wave),
+//     a 256-thread workgroup owns a 32x8 strip; the grid is (ceil(W/32), row tiles) so it is
+//     >> 256 workgroups at every benchmark resolution;
+//   * Object[] is indexed with a wave-uniform loop counter, so the matrices arrive through the
+//     scalar cache into SGPRs (s_load) and are broadcast for free; per-frame constants that do
+//     not depend on the pixel (aspect ratio, hable(white_point)) are computed once on the host
+//     with the same IEEE operations;
+//   * 16 B/pixel framebuffer stores are one global_store_dwordx4 per lane; the multi-GPU variant
+//     writes only the 4-B packed colour into a compact plane.
+// fp32 arithmetic order is that of the reference expression by expression (see the oracle for the
+// built-in semantics); UB of the reference is neutralised exactly as in oracle/rpt_oracle.c.
+#pragma once
+#include "../../include/rpt_layout.h"
+#include "rpt_device_math.hip.h"
+
+#pragma clang fp contract(off)
+
+namespace rptd {
+
+#define RPT_EPSILON 0.0000001f       /* opencl_kernel.cl:6 */
+#define RPT_MAX_LEAF_STEPS 4096
+#define RPT_PI_D 3.14159265358979323846264338327950288   /* OpenCL C M_PI (double) */
+
+struct KernelArgs {
+    const rpt_object *objects;
+    const rpt_float3 *vertices;
+    const rpt_float3 *normals;
+    const rpt_float2 *uvs;
+    const uint32_t *triangles;
+    const rpt_octree *octrees;
+    const int32_t *octreeTris;
+    const uint8_t *textures;
+    long long texture_bytes;
+    rpt_pixel *out16;        // 16 B/pixel framebuffer (full frame addressing) or null
+    uint32_t *plane;         // compact 4 B/pixel colour plane (local tile addressing) or null
+    float *debug_rgb;        // 3 floats/pixel, full frame addressing, or null
+    float hable_wp[3];       // hable(white_point), host-computed
+    float ambient;
+    float aspect;            // (float)width / (float)height
+    int object_count;
+    int width, height;
+    int interval;
+    int first_tile, tile_step;
+};
+
+struct Hit {                 // opencl_kernel.cl:38-44
+    float dist;
+    f3 normal;
+    f2 uv;
+    int object;
+};
+
+struct Ray { f3 origin, dir; };
+
+// ---------------------------------------------------------------------------------------------
+// opencl_kernel.cl:55-73
+RPT_DEV f3 createCamRayDir(float x_coord, float y_coord, int width, int height, float aspect_ratio) {
+    const float fx = x_coord / (float)width;
+    const float fy = y_coord / (float)height;
+    const float fx2 = (fx - 0.5f) * aspect_ratio;
+    const float fy2 = fy - 0.5f;
+    return normalize(mk3(fx2, fy2, 0.5f));
+}
+
+// opencl_kernel.cl:106-126
+RPT_DEV bool intersect_triangle(f3 A, f3 B, f3 C, const Ray &ray, float &dist, f2 &uv) {
+    const f3 v0v1 = B - A;
+    const f3 v0v2 = C - A;
+    const f3 pvec = cross(ray.dir, v0v2);
+    const float det = dot(v0v1, pvec);
+    if (det < RPT_EPSILON && -RPT_EPSILON < det) return false;
+    const float invDet = 1 / det;
+    const f3 tvec = ray.origin - A;
+    uv.x = dot(tvec, pvec) * invDet;
+    if (uv.x < 0 || uv.x > 1) return false;
+    const f3 qvec = cross(tvec, v0v1);
+    uv.y = dot(ray.dir, qvec) * invDet;
+    if (uv.y < 0 || uv.x + uv.y > 1) return false;
+    dist = dot(v0v2, qvec) * invDet;
+    return true;
+}
+
+// opencl_kernel.cl:128-170.  bounds[sign] is written as a select so nothing is indexed dynamically.
+RPT_DEV bool intersect_AABB(f3 bmin, f3 bmax, const Ray &ray, f2 &d, int &closeSide, int &farSide) {
+    const f3 origin = ray.origin;
+    const f3 inv_dir = mk3(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);
+    const int sx = inv_dir.x < 0 ? 1 : 0, sy = inv_dir.y < 0 ? 1 : 0, sz = inv_dir.z < 0 ? 1 : 0;
+    d.x = ((sx ? bmax.x : bmin.x) - origin.x) * inv_dir.x;
+    d.y = ((sx ? bmin.x : bmax.x) - origin.x) * inv_dir.x;
+    closeSide = 2 + sx;
+    farSide = 3 - sx;
+    const float tymin = ((sy ? bmax.y : bmin.y) - origin.y) * inv_dir.y;
+    const float tymax = ((sy ? bmin.y : bmax.y) - origin.y) * inv_dir.y;
+    if ((d.x > tymax) || (tymin > d.y)) return false;
+    if (tymin > d.x) { d.x = tymin; closeSide = 4 + sy; }
+    if (tymax < d.y) { d.y = tymax; farSide = 5 - sy; }
+    const float tzmin = ((sz ? bmax.z : bmin.z) - origin.z) * inv_dir.z;
+    const float tzmax = ((sz ? bmin.z : bmax.z) - origin.z) * inv_dir.z;
+    if ((d.x > tzmax) || (tzmin > d.y)) return false;
+    if (tzmin > d.x) { d.x = tzmin; closeSide = sz; }
+    if (tzmax < d.y) { d.y = tzmax; farSide = 1 - sz; }
+    return d.y > 0;
+}
+
+// opencl_kernel.cl:172-198 with the direction reciprocals and signs hoisted out of the leaf walk
+// (scaledDir is constant along one traversal, so 1/scaledDir is computed once: same values).
+struct ExitPlan { f3 scaledDir, inv_dir; int sx, sy, sz; };
+
+RPT_DEV ExitPlan makeExitPlan(f3 scaledDir) {
+    ExitPlan p;
+    p.scaledDir = scaledDir;
+    p.inv_dir = mk3(1.0f / scaledDir.x, 1.0f / scaledDir.y, 1.0f / scaledDir.z);
+    p.sx = p.inv_dir.x < 0;
+    p.sy = p.inv_dir.y < 0;
+    p.sz = p.inv_dir.z < 0;
+    return p;
+}
+
+RPT_DEV int getOppositeBoxSide(const ExitPlan &p, f3 &uv) {
+    const float dx = ((float)(1 - p.sx) - uv.x) * p.inv_dir.x;
+    const float dy = ((float)(1 - p.sy) - uv.y) * p.inv_dir.y;
+    const float dz = ((float)(1 - p.sz) - uv.z) * p.inv_dir.z;
+    float t;
+    int side;
+    if (dx < dy) {
+        if (dx < dz) { t = dx; side = 3 - p.sx; } else { t = dz; side = 1 - p.sz; }
+    } else {
+        if (dy < dz) { t = dy; side = 5 - p.sy; } else { t = dz; side = 1 - p.sz; }
+    }
+    uv = uv + p.scaledDir * t;
+    return side;
+}
+
+// child selection and re-normalisation of opencl_kernel.cl:237-238 / 257-258
+RPT_DEV int octree_child_step(f3 &uv) {
+    const float fidx = __builtin_roundf(uv.z) + 2 * __builtin_roundf(uv.y) + 4 * __builtin_roundf(uv.x);
+    const int childIndex = !(fidx >= 0.0f) ? 0 : (fidx > 7.0f ? 7 : (int)fidx);
+    uv.x = 2.0f * fmod_half(cl_min(uv.x, 1.0f - RPT_EPSILON));
+    uv.y = 2.0f * fmod_half(cl_min(uv.y, 1.0f - RPT_EPSILON));
+    uv.z = 2.0f * fmod_half(cl_min(uv.z, 1.0f - RPT_EPSILON));
+    return childIndex;
+}
+
+// opencl_kernel.cl:200-308, reading the reference's 96-B nodes field by field: a traversal step
+// needs min/max, (trisIndex,trisCount), children[0], one children[k] and one neighbors[k], not the
+// whole struct the reference copies.
+RPT_DEV bool intersect_octree(const KernelArgs &a, const rpt_object &obj, f4 origin4, f4 dir4, Hit &hit) {
+    const rpt_octree *__restrict__ octrees = a.octrees;
+    Ray newRay;
+    newRay.origin = transformPoint(obj.InvM, yzw(origin4));
+    newRay.dir = transformDirection(obj.InvM, yzw(dir4));
+    const float scale = length(newRay.dir);
+    newRay.dir = newRay.dir / scale;
+
+    int currOctreeIndex = obj.meshIndex;
+    f2 d;
+    int closeSide, farSide;
+    f3 nmin = ld3(octrees[currOctreeIndex].min), nmax = ld3(octrees[currOctreeIndex].max);
+    if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
+    f3 uv = newRay.origin + newRay.dir * d.x;
+
+    if (d.x < 0) {   // ray starts inside the root: descend to the leaf holding the origin
+        uv = (newRay.origin - nmin) / (nmax - nmin);
+        while (octrees[currOctreeIndex].children[0] != -1) {
+            const int childIndex = octree_child_step(uv);
+            currOctreeIndex = octrees[currOctreeIndex].children[childIndex];
+        }
+        nmin = ld3(octrees[currOctreeIndex].min);
+        nmax = ld3(octrees[currOctreeIndex].max);
+        if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
+        uv = newRay.origin + newRay.dir * d.x;
+    }
+
+    const ExitPlan plan = makeExitPlan(normalize(newRay.dir / (nmax - nmin)));
+    bool didHit = false;
+    int hitTri = 0;
+    int steps = 0;
+    while (currOctreeIndex != -1) {
+        if (++steps > RPT_MAX_LEAF_STEPS) break;
+        nmin = ld3(octrees[currOctreeIndex].min);
+        nmax = ld3(octrees[currOctreeIndex].max);
+        uv = (uv - nmin) / (nmax - nmin);
+        bool descended = false;
+        while (octrees[currOctreeIndex].children[0] != -1) {
+            const int childIndex = octree_child_step(uv);
+            currOctreeIndex = octrees[currOctreeIndex].children[childIndex];
+            descended = true;
+        }
+        if (descended) {
+            nmin = ld3(octrees[currOctreeIndex].min);
+            nmax = ld3(octrees[currOctreeIndex].max);
+        }
+        const int trisIndex = octrees[currOctreeIndex].trisIndex;
+        const int trisEnd = trisIndex + octrees[currOctreeIndex].trisCount;
+        for (int i = trisIndex; i < trisEnd; i++) {
+            const int tri = a.octreeTris[i];
+            const f3 A = ld3(a.vertices[a.triangles[9 * tri + 3 * 0]]);
+            const f3 B = ld3(a.vertices[a.triangles[9 * tri + 3 * 1]]);
+            const f3 C = ld3(a.vertices[a.triangles[9 * tri + 3 * 2]]);
+            float dist;
+            f2 triUV;
+            if (intersect_triangle(A, B, C, newRay, dist, triUV)) {
+                if (0 <= dist && dist < hit.dist) {
+                    hitTri = tri;
+                    hit.dist = dist;
+                    hit.uv = triUV;
+                    didHit = true;
+                }
+            }
+        }
+        const f3 extents = nmax - nmin;
+        farSide = getOppositeBoxSide(plan, uv);
+        uv = nmin + uv * extents;
+        currOctreeIndex = octrees[currOctreeIndex].neighbors[farSide];
+        if (length(uv - newRay.origin) > hit.dist) break;
+    }
+    if (!didHit) return false;
+
+    const float u = hit.uv.x, v = hit.uv.y;
+    const float w = 1.0f - u - v;
+    const f3 normA = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 0]]);
+    const f3 normB = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 1]]);
+    const f3 normC = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 2]]);
+    hit.normal = normalize(applyTranspose(obj.InvM, normA * w + normB * u + normC * v));
+    const rpt_float2 uvA = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 0]];
+    const rpt_float2 uvB = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 1]];
+    const rpt_float2 uvC = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 2]];
+    hit.uv.x = w * uvA.x + u * uvB.x + v * uvC.x;
+    hit.uv.y = w * uvA.y + u * uvB.y + v * uvC.y;
+    const f3 objPoint = newRay.origin + newRay.dir * hit.dist;
+    const f3 worldPoint = transformPoint(obj.M, objPoint);
+    hit.dist = length(worldPoint - yzw(origin4)) / length(yzw(dir4));
+    return true;
+}
+
+RPT_DEV float max3(f3 v) { return cl_max(cl_max(v.x, v.y), v.z); }   // opencl_kernel.cl:310
+
+// opencl_kernel.cl:312-333
+RPT_DEV bool intersect_cube(const rpt_object &obj, f4 origin4, f4 dir4, Hit &hit) {
+    const f3 origin = transformPoint(obj.InvM, yzw(origin4));
+    f3 dir = transformDirection(obj.InvM, yzw(dir4));
+    const float scale = length(dir);
+    dir = dir / scale;
+    const float winding = max3(mk3(__builtin_fabsf(origin.x), __builtin_fabsf(origin.y), __builtin_fabsf(origin.z))) < 1.0f ? -1.0f : 1.0f;
+    f3 sgn = mk3(-cl_sign(dir.x), -cl_sign(dir.y), -cl_sign(dir.z));
+    const f3 d = (sgn * winding - origin) / dir;
+#define RPT_TEST(U, V, W) ((d.U >= 0.0f) && (__builtin_fabsf(origin.V + dir.V * d.U) < 1.0f) && (__builtin_fabsf(origin.W + dir.W * d.U) < 1.0f))
+    if (RPT_TEST(x, y, z)) sgn = mk3(sgn.x, 0, 0);
+    else if (RPT_TEST(y, z, x)) sgn = mk3(0, sgn.y, 0);
+    else sgn = mk3(0, 0, RPT_TEST(z, x, y) ? sgn.z : 0);
+#undef RPT_TEST
+    const bool any = (sgn.x != 0) || (sgn.y != 0) || (sgn.z != 0);
+    if (!any) return false;          // the reference fills hit with NaNs here and discards it
+    const float dist = (sgn.x != 0) ? d.x : ((sgn.y != 0) ? d.y : d.z);
+    const f3 objPt = origin + dir * dist;
+    hit.dist = dist / scale;
+    hit.normal = normalize(applyTranspose(obj.InvM, sgn));
+    if (sgn.x != 0) { hit.uv.x = (objPt.y + 1) / 2; hit.uv.y = (objPt.z + 1) / 2; }
+    else if (sgn.y != 0) { hit.uv.x = (objPt.x + 1) / 2; hit.uv.y = (objPt.z + 1) / 2; }
+    else { hit.uv.x = (objPt.x + 1) / 2; hit.uv.y = (objPt.y + 1) / 2; }
+    return true;
+}
+
+// opencl_kernel.cl:335-359.  The (u,v) of a sphere hit is only ever consumed by the texture
+// fetch, so it is evaluated only for textured spheres (want_uv); the double-precision divide by
+// M_PI is the reference's (M_PI is a double constant in OpenCL C).
+RPT_DEV bool intersect_sphere(const rpt_object &obj, f4 origin4, f4 dir4, Hit &hit, bool want_uv) {
+    const f3 rayToSphere = -transformPoint(obj.InvM, yzw(origin4));
+    f3 dir = transformDirection(obj.InvM, yzw(dir4));
+    const float scale = length(dir);
+    dir = dir / scale;
+    const float b = dot(rayToSphere, dir);
+    const float c = dot(rayToSphere, rayToSphere) - 1.0f;
+    float disc = b * b - c;
+    if (disc < 0.0f) return false;
+    disc = __builtin_sqrtf(disc);
+    float dist;
+    if ((b - disc) > RPT_EPSILON) dist = b - disc;
+    else if ((b + disc) > RPT_EPSILON) dist = b + disc;
+    else return false;
+    const f3 objPt = -rayToSphere + dir * dist;
+    hit.dist = dist / scale;
+    hit.normal = normalize(applyTranspose(obj.InvM, objPt));
+    if (want_uv) {
+        hit.uv.x = (float)(0.5f + atan2f(objPt.z, objPt.x) / (2 * RPT_PI_D));
+        hit.uv.y = (float)(asinf(objPt.y) / RPT_PI_D + 0.5f);
+    } else {
+        hit.uv.x = 0.0f;
+        hit.uv.y = 0.0f;
+    }
+    return true;
+}
+
+RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, Hit &hit) {
+    const rpt_object &obj = a.objects[i];
+    switch (obj.type) {
+    case RPT_SPHERE: return intersect_sphere(obj, origin4, dir4, hit, obj.textureIndex != -1);
+    case RPT_CUBE:   return intersect_cube(obj, origin4, dir4, hit);
+    case RPT_MESH:   return intersect_octree(a, obj, origin4, dir4, hit);
+    default:         return false;
+    }
+}
+
+RPT_DEV float texel(const KernelArgs &a, long long addr) {
+    addr = addr < 0 ? 0 : addr;
+    addr = addr >= a.texture_bytes ? a.texture_bytes - 1 : addr;
+    return a.textures[addr] / 255.0f;
+}
+RPT_DEV f3 texel3(const KernelArgs &a, int offset, int width, int x, int y) {
+    const long long base = (long long)offset + 3 * ((long long)width * y + x);
+    return mk3(texel(a, base + 0), texel(a, base + 1), texel(a, base + 2));
+}
+
+// bilinear RGB8 fetch of opencl_kernel.cl:427-471 (upper clamps only; the odd 4th tap is the reference's)
+RPT_DEV f3 sample_texture(const KernelArgs &a, const rpt_object &ho, f2 huv) {
+    const int width = ho.textureWidth;
+    const int height = ho.textureHeight;
+    const float u = width * huv.x;
+    const float v = height * (1.0f - huv.y);
+    int x = imin(f2i_sat(__builtin_floorf(u)), width - 1);
+    int y = imin(f2i_sat(__builtin_floorf(v)), height - 1);
+    const float u_ratio = u - x;
+    const float v_ratio = v - y;
+    const float u_opp = 1 - u_ratio;
+    const float v_opp = 1 - v_ratio;
+    const int offset = ho.textureIndex;
+    f3 result = texel3(a, offset, width, x, y) * u_opp;
+    x = iclamp(x + 1, 0, width - 1);
+    result = result + texel3(a, offset, width, x, y) * u_ratio;
+    result = result * v_opp;
+    y = iclamp(y + 1, 0, height - 1);
+    f3 result2 = texel3(a, offset, width, x, y) * u_ratio;
+    x = iclamp(x - 1, 0, width - 1);
+    result2 = result2 + texel3(a, offset, width, x, y) * u_opp;
+    result2 = result2 * v_ratio;
+    return result + result2;
+}
+
+// opencl_kernel.cl:488-545: true when something other than the light blocks the segment
+RPT_DEV bool sample_light_occluded(const KernelArgs &a, f4 origin4, f4 dir4, float lightDist, int lightIndex) {
+    const f3 nd = normalize(yzw(dir4));
+    const f4 lightDir0 = mk4((float)a.interval, nd.x, nd.y, nd.z);
+    for (int i = 0; i < a.object_count; i++) {
+        if (i != lightIndex) {
+            Hit newHit;
+            newHit.dist = 1e20f;
+            const f4 newEvent0 = transformPoint4D(a.objects[i].Lorentz, origin4);
+            const f4 lightDir = transformPoint4D(a.objects[i].Lorentz, lightDir0);
+            if (intersect_object(a, i, newEvent0, lightDir, newHit)) {
+                if (newHit.dist < lightDist) return true;
+            }
+        }
+    }
+    return false;
+}
+
+// opencl_kernel.cl:361-486 + 548-604: closest hit over the object list, surface colour, lights
+RPT_DEV f3 trace(const KernelArgs &a, f3 camdir) {
+    const float inf = 1e20f;
+    Hit hit;
+    hit.dist = inf;
+    hit.object = -1;
+    f4 event = mk4(0, 0, 0, 0);
+    const f3 nd = normalize(camdir);
+    const f4 rayDir = mk4((float)a.interval, nd.x, nd.y, nd.z);
+
+    for (int i = 0; i < a.object_count; i++) {
+        Hit newHit;
+        newHit.dist = inf;
+        const f4 newEvent0 = ld4(a.objects[i].stationaryCam);
+        const f4 lightDir = transformPoint4D(a.objects[i].Lorentz, rayDir);
+        if (intersect_object(a, i, newEvent0, lightDir, newHit)) {
+            if (newHit.dist < hit.dist) {
+                event = newEvent0 + lightDir * newHit.dist;
+                hit = newHit;
+                hit.object = i;
+            }
+        }
+    }
+    if (hit.object < 0) return mk3(0.15f, 0.15f, 0.25f);
+
+    const rpt_object &ho = a.objects[hit.object];
+    f3 hcolor = ho.textureIndex != -1 ? sample_texture(a, ho, hit.uv) : ld3(ho.color);
+    if (ho.flashPeriod > 0) {   // proper-time flash, opencl_kernel.cl:476-482
+        const float period = ho.flashPeriod;
+        const float duration = ho.flashDuration;
+        if (event.x - period * __builtin_floorf(event.x / period) < duration) hcolor = hcolor * 2;
+    }
+
+    f3 color = hcolor * (a.interval != 0 ? a.ambient : 1.0f);
+    if (ho.light) color = color + hcolor;
+    if (a.interval != 0) {
+        for (int i = 0; i < a.object_count; i++) {
+            if (i != hit.object && a.objects[i].light) {
+                const rpt_object &lo = a.objects[i];
+                const f4 cameraPos_ObjFrame = ld4(ho.stationaryCam);
+                const f4 rayDir_ObjFrame = transformPoint4D(ho.Lorentz, rayDir);
+                f4 hitPos_ObjFrame = cameraPos_ObjFrame + rayDir_ObjFrame * hit.dist;
+                hitPos_ObjFrame = hitPos_ObjFrame + mk4(0, hit.normal.x * 0.001f, hit.normal.y * 0.001f, hit.normal.z * 0.001f);
+                const f4 hitPos = transformPoint4D(ho.InvLorentz, hitPos_ObjFrame);
+                const f4 hitPos_LightFrame = transformPoint4D(lo.Lorentz, hitPos);
+                const f3 lightPos3_LightFrame = mk3(lo.M[0].w, lo.M[1].w, lo.M[2].w);
+                const f3 lightDir3_LightFrame = lightPos3_LightFrame - yzw(hitPos_LightFrame);
+                const f4 lightDir_LightFrame = mk4(a.interval * length(lightDir3_LightFrame), lightDir3_LightFrame.x,
+                                                   lightDir3_LightFrame.y, lightDir3_LightFrame.z);
+                const f4 lightDir = transformPoint4D(lo.InvLorentz, lightDir_LightFrame);
+                const f4 lightDir_ObjFrame = transformPoint4D(ho.Lorentz, lightDir);
+                const f3 lightDir3_ObjFrame = yzw(lightDir_ObjFrame);
+                const f3 unitLightDir3 = normalize(lightDir3_ObjFrame);
+                const float ndotl = dot(hit.normal, unitLightDir3);
+                if (ndotl > 0) {
+                    const f3 ld = normalize(yzw(lightDir));
+                    const f4 shadowDir = mk4((float)a.interval, ld.x, ld.y, ld.z);
+                    if (!sample_light_occluded(a, hitPos, shadowDir, length(yzw(lightDir)), i)) {
+                        const float k = ndotl / (1.0f + 0.1f * length(lightDir3_ObjFrame) +
+                                                 0.01f * dot(lightDir3_ObjFrame, lightDir3_ObjFrame));
+                        color = color + hcolor * k * ld3(lo.color);
+                    }
+                }
+            }
+        }
+    }
+    return color;
+}
+
+// opencl_kernel.cl:607-616
+RPT_DEV float hable1(float x) {
+    const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+    return ((x * (A * x + C * B) + D * E) / (x * (A * x + B) + D * F)) - E / F;
+}
+
+RPT_DEV uint32_t to_u8(float c) {   // (unsigned char)(c * 255): saturating, NaN -> 0
+    const float t = c * 255;
+    if (!(t == t)) return 0u;
+    if (t <= 0.0f) return 0u;
+    if (t >= 255.0f) return 255u;
+    return (uint32_t)(int)t;
+}
+
+// tonemap + pack of opencl_kernel.cl:649-657; returns the little-endian R,G,B,1 word
+RPT_DEV uint32_t tonemap_pack(const KernelArgs &a, f3 color, f3 &mapped) {
+    mapped.x = cl_min(hable1(color.x) / a.hable_wp[0], 1.0f);
+    mapped.y = cl_min(hable1(color.y) / a.hable_wp[1], 1.0f);
+    mapped.z = cl_min(hable1(color.z) / a.hable_wp[2], 1.0f);
+    return to_u8(mapped.x) | (to_u8(mapped.y) << 8) | (to_u8(mapped.z) << 16) | (1u << 24);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Variant 1: one thread per pixel, wave = 8x8 tile, workgroup = 32x8 strip.
+__global__ __launch_bounds__(256) void rpt_render_kernel(const KernelArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int x_coord = blockIdx.x * 32 + wave * 8 + (lane & 7);
+    const int local_row = blockIdx.y * RPT_TILE_ROWS + (lane >> 3);
+    const int y_coord = (a.first_tile + (int)blockIdx.y * a.tile_step) * RPT_TILE_ROWS + (lane >> 3);
+    if (x_coord >= a.width || y_coord >= a.height) return;   // the reference has no guard (UB)
+
+    const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);
+    const f3 color = trace(a, camdir);
+    f3 mapped;
+    const uint32_t packed = tonemap_pack(a, color, mapped);
+
+    const size_t id = (size_t)y_coord * a.width + x_coord;
+    if (a.out16) {
+        uint4 px;
+        px.x = __float_as_uint((float)x_coord);
+        px.y = __float_as_uint((float)y_coord);
+        px.z = packed;
+        px.w = 0u;
+        reinterpret_cast<uint4 *>(a.out16)[id] = px;
+    }
+    if (a.plane) a.plane[(size_t)local_row * a.width + x_coord] = packed;
+    if (a.debug_rgb) {
+        a.debug_rgb[3 * id + 0] = mapped.x;
+        a.debug_rgb[3 * id + 1] = mapped.y;
+        a.debug_rgb[3 * id + 2] = mapped.z;
+    }
+}
+
+// Root-side reassembly after the gather: plane of rank r, local tile k -> global tile r + k*n_ranks.
+__global__ __launch_bounds__(256) void rpt_scatter_plane_kernel(const uint32_t *planes, rpt_pixel *out16, int width,
+                                                               int height, int n_ranks, size_t plane_stride_words) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= width || y >= height) return;
+    const int tile = y / RPT_TILE_ROWS;
+    const int rank = tile % n_ranks;
+    const int local_row = (tile / n_ranks) * RPT_TILE_ROWS + (y % RPT_TILE_ROWS);
+    const uint32_t packed = planes[(size_t)rank * plane_stride_words + (size_t)local_row * width + x];
+    uint4 px;
+    px.x = __float_as_uint((float)x);
+    px.y = __float_as_uint((float)y);
+    px.z = packed;
+    px.w = 0u;
+    reinterpret_cast<uint4 *>(out16)[(size_t)y * width + x] = px;
+}
+
+// Known-answer probes of single device functions.
+__global__ void rpt_probe_kernel(int which, const float *in, float *out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (which == 0) {
+        const float *p = in + 15 * i;
+        Ray r;
+        r.origin = mk3(p[9], p[10], p[11]);
+        r.dir = mk3(p[12], p[13], p[14]);
+        float dist = 0;
+        f2 uv = {0, 0};
+        const bool h = intersect_triangle(mk3(p[0], p[1], p[2]), mk3(p[3], p[4], p[5]), mk3(p[6], p[7], p[8]), r, dist, uv);
+        out[4 * i + 0] = h ? 1.0f : 0.0f;
+        out[4 * i + 1] = h ? dist : 0;
+        out[4 * i + 2] = h ? uv.x : 0;
+        out[4 * i + 3] = h ? uv.y : 0;
+    } else if (which == 1) {
+        const float *p = in + 12 * i;
+        Ray r;
+        r.origin = mk3(p[6], p[7], p[8]);
+        r.dir = mk3(p[9], p[10], p[11]);
+        f2 d = {0, 0};
+        int cs = 0, fs = 0;
+        const bool h = intersect_AABB(mk3(p[0], p[1], p[2]), mk3(p[3], p[4], p[5]), r, d, cs, fs);
+        out[5 * i + 0] = h ? 1.0f : 0.0f;
+        out[5 * i + 1] = h ? d.x : 0;
+        out[5 * i + 2] = h ? d.y : 0;
+        out[5 * i + 3] = h ? (float)cs : 0;
+        out[5 * i + 4] = h ? (float)fs : 0;
+    } else if (which == 2) {
+        const float *p = in + 4 * i;
+        const int w = (int)p[2], hgt = (int)p[3];
+        const f3 dir = createCamRayDir(p[0], p[1], w, hgt, (float)w / (float)hgt);
+        out[3 * i + 0] = dir.x;
+        out[3 * i + 1] = dir.y;
+        out[3 * i + 2] = dir.z;
+    } else {
+        out[3 * i + 0] = hable1(in[3 * i + 0]);
+        out[3 * i + 1] = hable1(in[3 * i + 1]);
+        out[3 * i + 2] = hable1(in[3 * i + 2]);
+    }
+}
+
+}  // namespace rptd

@@ -1,0 +1,106 @@
+"""Multi-GPU frame sharding: pixel-row tiles across ranks + one gather.
+
+The reference is single-device.  Pixels are independent, scene buffers are small and read-only, so
+the path shards by replication: every rank holds the whole scene, renders the interleaved 8-row
+tiles ``rank, rank+N, rank+2N, ...`` (interleaving balances the expensive mesh rows) into a compact
+4 B/pixel colour plane — the x,y floats of the 16 B pixel are constants of the resolution, only the
+packed colour changes — and ONE gather (RCCL over xGMI, ``torch.distributed`` backend "nccl") brings
+the planes to rank 0, where ``rpt_scatter_colour_plane`` expands them into the reference's 16 B/pixel
+framebuffer.  No other collective is on the data path.
+
+The tile arithmetic below is pure Python/numpy so that it can be exercised on CPU (gloo) without a GPU.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+
+TILE_ROWS = 8
+
+
+def tile_count(height: int) -> int:
+    return (height + TILE_ROWS - 1) // TILE_ROWS
+
+
+def local_tile_count(height: int, rank: int, world: int) -> int:
+    tiles = tile_count(height)
+    return 0 if rank >= tiles else (tiles - rank + world - 1) // world
+
+
+def max_local_tiles(height: int, world: int) -> int:
+    return (tile_count(height) + world - 1) // world
+
+
+def plane_words(width: int, height: int, world: int) -> int:
+    """Words (u32) of one rank's padded colour plane: every rank sends the same count."""
+    return max_local_tiles(height, world) * TILE_ROWS * width
+
+
+def tile_rows_of_rank(height: int, rank: int, world: int) -> List[range]:
+    """Global row ranges (clipped to the image) rendered by `rank`, in local-tile order."""
+    out = []
+    for k in range(local_tile_count(height, rank, world)):
+        t = rank + k * world
+        out.append(range(t * TILE_ROWS, min((t + 1) * TILE_ROWS, height)))
+    return out
+
+
+def extract_plane(packed_frame: np.ndarray, width: int, height: int, rank: int, world: int) -> np.ndarray:
+    """The padded plane rank `rank` would send, cut out of a full frame of packed colours [H, W]."""
+    plane = np.zeros((max_local_tiles(height, world) * TILE_ROWS, width), dtype=np.uint32)
+    for k, rows in enumerate(tile_rows_of_rank(height, rank, world)):
+        plane[k * TILE_ROWS:k * TILE_ROWS + len(rows)] = packed_frame[rows.start:rows.stop]
+    return plane.reshape(-1)
+
+
+def reassemble_planes(planes: np.ndarray, width: int, height: int, world: int) -> np.ndarray:
+    """Host restatement of rpt_scatter_plane_kernel: [world, plane_words] -> 16 B/pixel framebuffer."""
+    from .renderer import PIXEL_DTYPE
+    planes = np.asarray(planes, dtype=np.uint32).reshape(world, -1)
+    out = np.zeros(height * width, dtype=PIXEL_DTYPE)
+    xs = np.arange(width, dtype=np.float32)
+    for y in range(height):
+        tile = y // TILE_ROWS
+        rank, local_row = tile % world, (tile // world) * TILE_ROWS + (y % TILE_ROWS)
+        row = planes[rank, local_row * width:(local_row + 1) * width]
+        sl = slice(y * width, (y + 1) * width)
+        out["x"][sl] = xs
+        out["y"][sl] = np.float32(y)
+        out["rgba"][sl] = row.view(np.uint8).reshape(width, 4)
+    return out
+
+
+class FrameSharder:
+    """Owns the output tensors of one rank and runs render (+ gather + scatter) for one frame."""
+
+    def __init__(self, renderer, width: int, height: int, rank: int, world: int):
+        import torch
+        self.r, self.W, self.H, self.rank, self.world = renderer, width, height, rank, world
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.framebuffer: Optional["torch.Tensor"] = None
+        self.local_rows = local_tile_count(height, rank, world) * TILE_ROWS
+        if world == 1:
+            renderer.set_rows(0, 1, False)
+            self.framebuffer = torch.zeros(width * height * 4, dtype=torch.int32, device=dev)
+            renderer.set_output(self.framebuffer.data_ptr())
+            self.plane = self.gathered = None
+        else:
+            words = plane_words(width, height, world)
+            renderer.set_rows(rank, world, True)
+            self.plane = torch.zeros(words, dtype=torch.int32, device=dev)
+            renderer.set_plane_output(self.plane.data_ptr())
+            if rank == 0:
+                self.gathered = torch.zeros((world, words), dtype=torch.int32, device=dev)
+                self.framebuffer = torch.zeros(width * height * 4, dtype=torch.int32, device=dev)
+            else:
+                self.gathered = None
+
+    def render_and_gather(self):
+        self.r.render_async()
+        if self.world > 1:
+            import torch.distributed as td
+            td.gather(self.plane, list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0)
+            if self.rank == 0:
+                self.r.scatter_colour_plane(self.gathered.data_ptr(), self.framebuffer.data_ptr(), self.W, self.H,
+                                            self.world, self.gathered.shape[1])

@@ -1,0 +1,169 @@
+"""Renderer — Python face of the C-ABI render path (include/rpt.h, librpt_hip.so).
+
+Mirrors the reference's device-runtime glue (CLSetup.h:22-26): ``initOpenCL`` -> ``Renderer()``,
+the eight buffer uploads of main.cpp:33-55 -> ``upload_scene``, ``initCLKernel`` ->
+``set_params``/``set_output``, the per-frame ``enqueueWriteBuffer(cl_objects)`` -> ``set_objects``,
+``runKernel`` -> ``render``.  Everything executes in the HIP library; there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from .scene import Scene
+
+PIXEL_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("rgba", "u1", (4,)), ("unspecified", "<u4")])
+TILE_ROWS = 8
+
+
+class RenderError(RuntimeError):
+    pass
+
+
+class Renderer:
+    def __init__(self, device: int = 0):
+        self._lib = _ffi.hip()
+        h = C.c_void_p()
+        rc = self._lib.rpt_create(C.byref(h), int(device))
+        if rc != 0 or not h:
+            raise RenderError(f"rpt_create(device={device}) failed with status {rc}: no usable gfx950 device "
+                              "(the render path has no CPU fallback)")
+        self._h = h
+        self.device = device
+        self.width = self.height = 0
+        self._rows = (0, 1, False)
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.rpt_destroy(h)
+
+    __del__ = close
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RenderError(f"{what} failed ({rc}): {self._lib.rpt_last_error(self._h).decode()}")
+
+    # -- reference enqueue sequence ------------------------------------------------------------
+    def upload_scene(self, scene: Scene):
+        d = scene.desc()
+        self._check(self._lib.rpt_upload_scene(self._h, C.byref(d)), "rpt_upload_scene")
+
+    def upload_desc(self, desc: _ffi.SceneDesc):
+        self._check(self._lib.rpt_upload_scene(self._h, C.byref(desc)), "rpt_upload_scene")
+
+    def set_objects(self, scene_or_bytes):
+        if isinstance(scene_or_bytes, Scene):
+            d = scene_or_bytes.desc()
+            self._check(self._lib.rpt_set_objects(self._h, d.objects, d.object_count), "rpt_set_objects")
+        else:
+            raw = np.ascontiguousarray(scene_or_bytes).view(np.uint8)
+            assert raw.size % 320 == 0
+            self._check(self._lib.rpt_set_objects(self._h, raw.ctypes.data, raw.size // 320), "rpt_set_objects")
+
+    def set_params(self, white_point: Sequence[float], ambient: float, width: int, height: int, interval: int):
+        wp = (C.c_float * 3)(*white_point)
+        self._check(self._lib.rpt_set_params(self._h, wp, float(ambient), int(width), int(height), int(interval)),
+                    "rpt_set_params")
+        self.width, self.height = int(width), int(height)
+
+    def set_scene_params(self, scene: Scene, width: int, height: int):
+        p = scene.params
+        self.set_params(p["white_point"], p["ambient"], width, height, p["interval"])
+
+    def set_output(self, device_ptr: Optional[int]):
+        self._check(self._lib.rpt_set_output(self._h, C.c_void_p(device_ptr or 0)), "rpt_set_output")
+
+    def set_rows(self, first_tile: int = 0, tile_step: int = 1, colour_plane: bool = False):
+        self._check(self._lib.rpt_set_rows(self._h, first_tile, tile_step, int(colour_plane)), "rpt_set_rows")
+        self._rows = (first_tile, tile_step, colour_plane)
+
+    def set_plane_output(self, device_ptr: Optional[int]):
+        self._check(self._lib.rpt_set_plane_output(self._h, C.c_void_p(device_ptr or 0)), "rpt_set_plane_output")
+
+    def set_stream(self, hip_stream: Optional[int]):
+        self._check(self._lib.rpt_set_stream(self._h, C.c_void_p(hip_stream or 0)), "rpt_set_stream")
+
+    def set_debug_rgb(self, enable: bool = True):
+        self._check(self._lib.rpt_set_debug_rgb(self._h, C.c_void_p(1 if enable else 0)), "rpt_set_debug_rgb")
+
+    def set_variant(self, variant: int):
+        self._check(self._lib.rpt_set_variant(self._h, int(variant)), "rpt_set_variant")
+
+    def render(self):
+        self._check(self._lib.rpt_render(self._h), "rpt_render")
+
+    def render_async(self):
+        self._check(self._lib.rpt_render_async(self._h), "rpt_render_async")
+
+    def sync(self):
+        self._check(self._lib.rpt_sync(self._h), "rpt_sync")
+
+    # -- results -------------------------------------------------------------------------------
+    def local_tiles(self) -> int:
+        first, step, _ = self._rows
+        tiles = (self.height + TILE_ROWS - 1) // TILE_ROWS
+        return 0 if first >= tiles else (tiles - first + step - 1) // step
+
+    def output_ptr(self) -> int:
+        return self._lib.rpt_output_ptr(self._h) or 0
+
+    def colour_plane_ptr(self) -> int:
+        return self._lib.rpt_colour_plane_ptr(self._h) or 0
+
+    def read_framebuffer(self) -> np.ndarray:
+        """16 B/pixel framebuffer as a structured array [height*width] (row 0 = bottom row)."""
+        out = np.empty(self.width * self.height, dtype=PIXEL_DTYPE)
+        self._check(self._lib.rpt_read_framebuffer(self._h, out.ctypes.data, out.nbytes), "rpt_read_framebuffer")
+        return out
+
+    def read_colour_plane(self) -> np.ndarray:
+        out = np.empty((self.local_tiles() * TILE_ROWS, self.width), dtype=np.uint32)
+        self._check(self._lib.rpt_read_framebuffer(self._h, out.ctypes.data, out.nbytes), "rpt_read_framebuffer")
+        return out
+
+    def read_debug_rgb(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        self._check(self._lib.rpt_read_debug_rgb(self._h, out.ctypes.data, out.nbytes), "rpt_read_debug_rgb")
+        return out
+
+    def last_frame_ms(self) -> float:
+        ms = C.c_float()
+        self._check(self._lib.rpt_last_frame_ms(self._h, C.byref(ms)), "rpt_last_frame_ms")
+        return ms.value
+
+    def timed_frames(self, frames: int) -> float:
+        ms = C.c_float()
+        self._check(self._lib.rpt_timed_frames(self._h, int(frames), C.byref(ms)), "rpt_timed_frames")
+        return ms.value
+
+    def scatter_colour_plane(self, planes_ptr: int, out16_ptr: int, width: int, height: int, n_ranks: int,
+                             plane_stride_words: int):
+        self._check(self._lib.rpt_scatter_colour_plane(self._h, C.c_void_p(planes_ptr), C.c_void_p(out16_ptr), width,
+                                                       height, n_ranks, plane_stride_words, 0),
+                    "rpt_scatter_colour_plane")
+
+    def probe(self, which: int, inputs: np.ndarray, out_width: int) -> np.ndarray:
+        inputs = np.ascontiguousarray(inputs, dtype=np.float32)
+        n = inputs.shape[0]
+        out = np.empty((n, out_width), dtype=np.float32)
+        self._check(self._lib.rpt_probe(self._h, which, inputs.ctypes.data, out.ctypes.data, n), "rpt_probe")
+        return out
+
+
+def render_scene(scene: Scene, width: int, height: int, device: int = 0, debug_rgb: bool = False):
+    """Convenience: upload, render one frame, read back. Returns (pixels, rgb-or-None)."""
+    r = Renderer(device)
+    try:
+        r.upload_scene(scene)
+        r.set_scene_params(scene, width, height)
+        r.set_output(None)
+        if debug_rgb:
+            r.set_debug_rgb(True)
+        r.render()
+        return r.read_framebuffer(), (r.read_debug_rgb() if debug_rgb else None)
+    finally:
+        r.close()
