@@ -116,6 +116,11 @@ int rpt_timing_end(rpt_ctx *ctx, float *total_ms, int *frames);
 int rpt_scatter_colour_plane(rpt_ctx *ctx, const void *planes, void *out16, int width, int height,
                              int n_ranks, int plane_stride_words, int reserved);
 
+/* Diagnostic variant 7 only: loop-iteration counters of the octree walk of the last frame —
+ * [0..2] leaf steps / triangle tests / descent steps summed over lanes, [3..5] the same counted
+ * once per executing wavefront (lane sum / (64 * wave count) = SIMD utilisation of that loop). */
+int rpt_read_counters(rpt_ctx *ctx, unsigned long long out[8]);
+
 /* Known-answer probes of individual device functions (tests): which = 0 intersect_triangle
  * (in 15 floats -> out 4), 1 intersect_AABB (12 -> 5), 2 createCamRay (4 -> 3), 3 hable (3 -> 3). */
 int rpt_probe(rpt_ctx *ctx, int which, const void *host_in, void *host_out, int n);

@@ -140,6 +140,7 @@ HIP_SYMBOLS = {
     "rpt_set_plane_output": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rpt_timing_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "rpt_timing_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "rpt_read_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rpt_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "rpt_version": (C.c_char_p, []),
 }

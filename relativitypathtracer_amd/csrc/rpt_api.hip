@@ -3,6 +3,7 @@
 // rpt_kernels.hip.h.  Replaces the reference's CLSetup.cpp / main.cpp:33-59 enqueue sequence.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -31,6 +32,9 @@ struct rpt_ctx {
     std::string error;
 
     DeviceBuffer objects, vertices, normals, uvs, triangles, octrees, octreeTris, textures;
+    DeviceBuffer counters;
+    DeviceBuffer dnodes, dtris, dobjs;        // derived layouts (rpt_kernels.hip.h)
+    bool compact_ok = false;                  // derived octree layout usable (children consecutive)
     DeviceBuffer owned_out, owned_plane, owned_rgb;
     void *pinned_objects = nullptr;
     size_t pinned_capacity = 0;
@@ -101,6 +105,14 @@ float hable_host(float x) {
     return ((x * (A * x + C * B) + D * E) / (x * (A * x + B) + D * F)) - E / F;
 }
 
+uint32_t to_u8_host(float c) {   // same definition as the kernel's to_u8
+    const float t = c * 255;
+    if (!(t == t)) return 0u;
+    if (t <= 0.0f) return 0u;
+    if (t >= 255.0f) return 255u;
+    return (uint32_t)(int)t;
+}
+
 // Every index the kernel will follow must stay inside its array: a GPU fault can reset the node.
 int validate_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
     if (s.triangle_words % RPT_TRI_STRIDE) return fail(ctx, RPT_ERR_SCENE, "triangles: word count is not a multiple of 9");
@@ -127,6 +139,76 @@ int validate_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
             if (n.neighbors[c] < -1 || n.neighbors[c] >= n_nodes) return fail(ctx, RPT_ERR_SCENE, "octree: neighbour index out of range");
     }
     return RPT_OK;
+}
+
+// Derived octree layout: one 64-B DNode per node and one 48-B DTri per leaf triangle reference.
+// Only the numbers the reference stores (and B-A, C-A, which intersect_triangle would form from
+// them with the same IEEE subtraction) go in, so traversal results are unchanged.
+int build_derived_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
+    ctx->compact_ok = false;
+    if (s.octree_count == 0) {
+        ctx->compact_ok = true;
+        if (int rc = reserve(ctx, ctx->dnodes, 0)) return rc;
+        return reserve(ctx, ctx->dtris, 0);
+    }
+    std::vector<rptd::DNode> nodes(s.octree_count);
+    std::vector<rptd::DTri> tris;
+    for (size_t i = 0; i < s.octree_count; i++) {
+        const rpt_octree &o = s.octrees[i];
+        rptd::DNode &n = nodes[i];
+        std::memset(&n, 0, sizeof n);
+        n.minx = o.min.x; n.miny = o.min.y; n.minz = o.min.z;
+        n.maxx = o.max.x; n.maxy = o.max.y; n.maxz = o.max.z;
+        n.firstChild = o.children[0];
+        if (o.children[0] != -1)
+            for (int c = 1; c < 8; c++)
+                if (o.children[c] != o.children[0] + c) return RPT_OK;   // not consecutive: keep the general kernel
+        for (int c = 0; c < 6; c++) n.nb[c] = o.neighbors[c];
+        n.leafBegin = (int)tris.size();
+        n.leafCount = 0;
+        if (o.children[0] == -1) {
+            n.leafCount = o.trisCount;
+            for (int k = o.trisIndex; k < o.trisIndex + o.trisCount; k++) {
+                const int t = s.octreeTris[k];
+                const rpt_float3 &A = s.vertices[s.triangles[9 * t + 0]];
+                const rpt_float3 &B = s.vertices[s.triangles[9 * t + 3]];
+                const rpt_float3 &C = s.vertices[s.triangles[9 * t + 6]];
+                rptd::DTri r;
+                std::memset(&r, 0, sizeof r);
+                r.ax = A.x; r.ay = A.y; r.az = A.z;
+                r.e1x = B.x - A.x; r.e1y = B.y - A.y; r.e1z = B.z - A.z;
+                r.e2x = C.x - A.x; r.e2y = C.y - A.y; r.e2z = C.z - A.z;
+                r.tri = t;
+                tris.push_back(r);
+            }
+        }
+    }
+    if (tris.size() > (size_t)0x7fffffff) return RPT_OK;
+    if (int rc = upload(ctx, ctx->dnodes, nodes.data(), nodes.size() * sizeof(rptd::DNode))) return rc;
+    if (int rc = upload(ctx, ctx->dtris, tris.data(), tris.size() * sizeof(rptd::DTri))) return rc;
+    ctx->compact_ok = true;
+    return RPT_OK;
+}
+
+// Per-frame DObj records: the primary-ray origin in each object's space and what follows from it
+// (opencl_kernel.cl:314,318 / 336,341), with the kernel's operation order.
+void build_dobjs(const rpt_object *objs, int count, rptd::DObj *out) {
+    for (int i = 0; i < count; i++) {
+        const rpt_object &o = objs[i];
+        const float vx = o.stationaryCam.y, vy = o.stationaryCam.z, vz = o.stationaryCam.w;
+        float p[3];
+        for (int r = 0; r < 3; r++) p[r] = o.InvM[r].x * vx + o.InvM[r].y * vy + o.InvM[r].z * vz + o.InvM[r].w * 1.0f;
+        rptd::DObj d;
+        std::memset(&d, 0, sizeof d);
+        d.ox = p[0]; d.oy = p[1]; d.oz = p[2];
+        const float rx = -p[0], ry = -p[1], rz = -p[2];
+        d.sphere_c = (rx * rx + ry * ry + rz * rz) - 1.0f;
+        const float ax = std::fabs(p[0]), ay = std::fabs(p[1]), az = std::fabs(p[2]);
+        const float m1 = ax < ay ? ay : ax;
+        const float m2 = m1 < az ? az : m1;
+        d.winding = m2 < 1.0f ? -1.0f : 1.0f;
+        out[i] = d;
+    }
 }
 
 int validate_objects(rpt_ctx *ctx, const rpt_object *objs, int count) {
@@ -176,6 +258,9 @@ int launch(rpt_ctx *ctx) {
 
     rptd::KernelArgs a;
     std::memset(&a, 0, sizeof a);
+    a.dnodes = (const rptd::DNode *)ctx->dnodes.ptr;
+    a.dtris = (const rptd::DTri *)ctx->dtris.ptr;
+    a.dobjs = (const rptd::DObj *)ctx->dobjs.ptr;
     a.objects = (const rpt_object *)ctx->objects.ptr;
     a.vertices = (const rpt_float3 *)ctx->vertices.ptr;
     a.normals = (const rpt_float3 *)ctx->normals.ptr;
@@ -189,6 +274,16 @@ int launch(rpt_ctx *ctx) {
     a.plane = ctx->colour_plane ? (uint32_t *)(ctx->external_plane ? ctx->external_plane : ctx->owned_plane.ptr) : nullptr;
     a.debug_rgb = (float *)(ctx->external_rgb ? ctx->external_rgb : (ctx->want_owned_rgb ? ctx->owned_rgb.ptr : nullptr));
     for (int c = 0; c < 3; c++) a.hable_wp[c] = hable_host(ctx->white_point[c]);
+    {   // background colour of opencl_kernel.cl:565 through the tonemap and pack of :649-657, once per frame
+        const float bg[3] = {0.15f, 0.15f, 0.25f};
+        uint32_t packed = 1u << 24;
+        for (int c = 0; c < 3; c++) {
+            const float m = hable_host(bg[c]) / a.hable_wp[c];
+            a.bg_mapped[c] = 1.0f < m ? 1.0f : m;
+            packed |= to_u8_host(a.bg_mapped[c]) << (8 * c);
+        }
+        a.bg_packed = packed;
+    }
     a.ambient = ctx->ambient;
     a.aspect = (float)ctx->width / (float)ctx->height;
     a.object_count = ctx->object_count;
@@ -201,7 +296,24 @@ int launch(rpt_ctx *ctx) {
     const int tiles = local_tile_count(ctx);
     if (tiles == 0) return RPT_OK;
     const dim3 grid((ctx->width + 31) / 32, tiles);
-    hipLaunchKernelGGL(rptd::rpt_render_kernel, grid, dim3(256), 0, ctx->stream, a);
+    // variant 0 = default: the derived-layout kernel when the octree allows it, else the general one
+    int v = ctx->variant == 0 ? 3 : ctx->variant;
+    if (!ctx->compact_ok) v = 1;
+    switch (v) {
+    case 1: hipLaunchKernelGGL(rptd::rpt_render_kernel_v0, grid, dim3(256), 0, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1, grid, dim3(256), 0, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_w4, grid, dim3(256), 0, ctx->stream, a); break;
+    case 4: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_w5, grid, dim3(256), 0, ctx->stream, a); break;
+    case 5: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_w6, grid, dim3(256), 0, ctx->stream, a); break;
+    case 6: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_w8, grid, dim3(256), 0, ctx->stream, a); break;
+    case 7:
+        if (int rc = reserve(ctx, ctx->counters, 8 * sizeof(unsigned long long))) return rc;
+        RPT_HIP(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        a.counters = (unsigned long long *)ctx->counters.ptr;
+        hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_diag, grid, dim3(256), 0, ctx->stream, a);
+        break;
+    default: return fail(ctx, RPT_ERR_ARG, "unknown kernel variant");
+    }
     RPT_HIP(ctx, hipGetLastError());
     return RPT_OK;
 }
@@ -236,7 +348,7 @@ void rpt_destroy(rpt_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     for (DeviceBuffer *b : {&ctx->objects, &ctx->vertices, &ctx->normals, &ctx->uvs, &ctx->triangles, &ctx->octrees,
-                            &ctx->octreeTris, &ctx->textures, &ctx->owned_out, &ctx->owned_plane, &ctx->owned_rgb})
+                            &ctx->octreeTris, &ctx->textures, &ctx->dnodes, &ctx->dtris, &ctx->dobjs, &ctx->counters, &ctx->owned_out, &ctx->owned_plane, &ctx->owned_rgb})
         release(*b);
     if (ctx->pinned_objects) (void)hipHostFree(ctx->pinned_objects);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -272,6 +384,7 @@ int rpt_upload_scene(rpt_ctx *ctx, const rpt_scene_desc *s) {
     ctx->triangle_words = s->triangle_words;
     ctx->octree_count = s->octree_count;
     ctx->octree_tri_count = s->octree_tri_count;
+    if (int rc = build_derived_geometry(ctx, *s)) return rc;
     ctx->scene_uploaded = true;
     const int rc = rpt_set_objects(ctx, s->objects, (int)s->object_count);
     if (rc) ctx->scene_uploaded = false;
@@ -284,21 +397,25 @@ int rpt_set_objects(rpt_ctx *ctx, const void *objects, int count) {
     RPT_HIP(ctx, hipSetDevice(ctx->device));
     if (int rc = validate_objects(ctx, (const rpt_object *)objects, count)) return rc;
     const size_t bytes = (size_t)count * sizeof(rpt_object);
-    if (bytes > ctx->pinned_capacity) {
+    const size_t dbytes = (size_t)count * sizeof(rptd::DObj);
+    if (bytes + dbytes > ctx->pinned_capacity) {
         if (ctx->pinned_objects) RPT_HIP(ctx, hipHostFree(ctx->pinned_objects));
         ctx->pinned_objects = nullptr;
         ctx->pinned_capacity = 0;
-        const size_t cap = bytes < 4096 ? 4096 : bytes * 2;
+        const size_t cap = (bytes + dbytes) < 4096 ? 4096 : (bytes + dbytes) * 2;
         RPT_HIP(ctx, hipHostMalloc(&ctx->pinned_objects, cap, hipHostMallocDefault));
         ctx->pinned_capacity = cap;
     }
-    if (bytes > ctx->objects.capacity) RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bytes > ctx->objects.capacity || dbytes > ctx->dobjs.capacity) RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (int rc = reserve(ctx, ctx->objects, bytes)) return rc;
+    if (int rc = reserve(ctx, ctx->dobjs, dbytes)) return rc;
     if (bytes) {
         // the staging copy must not be overwritten while a previous frame's transfer is in flight
         RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         std::memcpy(ctx->pinned_objects, objects, bytes);
+        build_dobjs((const rpt_object *)objects, count, (rptd::DObj *)((char *)ctx->pinned_objects + bytes));
         RPT_HIP(ctx, hipMemcpyAsync(ctx->objects.ptr, ctx->pinned_objects, bytes, hipMemcpyHostToDevice, ctx->stream));
+        RPT_HIP(ctx, hipMemcpyAsync(ctx->dobjs.ptr, (char *)ctx->pinned_objects + bytes, dbytes, hipMemcpyHostToDevice, ctx->stream));
     }
     ctx->object_count = count;
     return RPT_OK;
@@ -346,7 +463,7 @@ int rpt_set_debug_rgb(rpt_ctx *ctx, void *p) {
 }
 
 int rpt_set_variant(rpt_ctx *ctx, int variant) {
-    if (!ctx || variant < 0 || variant > 0) return RPT_ERR_ARG;
+    if (!ctx || variant < 0 || variant > 7) return RPT_ERR_ARG;
     ctx->variant = variant;
     return RPT_OK;
 }
@@ -486,6 +603,15 @@ int rpt_scatter_colour_plane(rpt_ctx *ctx, const void *planes, void *out16, int 
     hipLaunchKernelGGL(rptd::rpt_scatter_plane_kernel, grid, dim3(256), 0, ctx->stream, (const uint32_t *)planes,
                        (rpt_pixel *)out16, width, height, n_ranks, (size_t)plane_stride_words);
     RPT_HIP(ctx, hipGetLastError());
+    return RPT_OK;
+}
+
+int rpt_read_counters(rpt_ctx *ctx, unsigned long long out[8]) {
+    if (!ctx || !out) return RPT_ERR_ARG;
+    if (!ctx->counters.ptr) return fail(ctx, RPT_ERR_STATE, "rpt_read_counters: render with the diagnostic variant (7) first");
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RPT_HIP(ctx, hipMemcpy(out, ctx->counters.ptr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RPT_OK;
 }
 

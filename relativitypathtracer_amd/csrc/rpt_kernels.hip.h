@@ -25,7 +25,31 @@ namespace rptd {
 #define RPT_MAX_LEAF_STEPS 4096
 #define RPT_PI_D 3.14159265358979323846264338327950288   /* OpenCL C M_PI (double) */
 
+// ---- derived, device-only layouts (built by the library at upload / per frame; values are the
+// reference's own numbers or IEEE results of the reference's own operations, so nothing rounds
+// differently) ----------------------------------------------------------------------------------
+// One octree node in one 64-B line.  Children of a node are consecutive in the reference's builder
+// (Octree.cpp:191-211 pushes the eight children back to back), so children[k] = firstChild + k.
+struct alignas(64) DNode {
+    float minx, miny, minz; int firstChild;      // -1 = leaf
+    float maxx, maxy, maxz; int leafBegin;       // first DTri of a leaf
+    int leafCount; int nb[6]; int pad;           // neighbours -z,+z,-x,+x,-y,+y
+};
+static_assert(sizeof(DNode) == 64, "DNode is one 64-B line");
+// One leaf triangle reference, gathered: A, B-A, C-A (the ray-independent part of
+// intersect_triangle, opencl_kernel.cl:108-109) and the triangle id, instead of the
+// octreeTris -> triangles -> vertices chain of three dependent loads.
+struct alignas(16) DTri { float ax, ay, az, e1x; float e1y, e1z, e2x, e2y; float e2z; int tri; int pad0, pad1; };
+static_assert(sizeof(DTri) == 48, "DTri is three 16-B loads");
+// Per object, per frame: the primary-ray origin in object space (every primary ray of a frame
+// starts at the camera event, opencl_kernel.cl:386-389) and what follows from it alone.
+struct alignas(16) DObj { float ox, oy, oz; float sphere_c; float winding; int pad0, pad1, pad2; };
+static_assert(sizeof(DObj) == 32, "DObj");
+
 struct KernelArgs {
+    const DNode *dnodes;
+    const DTri *dtris;
+    const DObj *dobjs;
     const rpt_object *objects;
     const rpt_float3 *vertices;
     const rpt_float3 *normals;
@@ -38,7 +62,11 @@ struct KernelArgs {
     rpt_pixel *out16;        // 16 B/pixel framebuffer (full frame addressing) or null
     uint32_t *plane;         // compact 4 B/pixel colour plane (local tile addressing) or null
     float *debug_rgb;        // 3 floats/pixel, full frame addressing, or null
+    unsigned long long *counters;   // diagnostic builds only (variant 7): [0..2] lane-level leaf/tri/descent
+                                    // iterations, [3..5] the same counted once per executing wave
     float hable_wp[3];       // hable(white_point), host-computed
+    float bg_mapped[3];      // min(hable(background)/hable(white_point), 1): what every miss pixel maps to
+    uint32_t bg_packed;      // its packed R,G,B,1 word
     float ambient;
     float aspect;            // (float)width / (float)height
     int object_count;
@@ -145,32 +173,126 @@ RPT_DEV int octree_child_step(f3 &uv) {
     return childIndex;
 }
 
-// opencl_kernel.cl:200-308, reading the reference's 96-B nodes field by field: a traversal step
-// needs min/max, (trisIndex,trisCount), children[0], one children[k] and one neighbors[k], not the
-// whole struct the reference copies.
-RPT_DEV bool intersect_octree(const KernelArgs &a, const rpt_object &obj, f4 origin4, f4 dir4, Hit &hit) {
-    const rpt_octree *__restrict__ octrees = a.octrees;
-    Ray newRay;
-    newRay.origin = transformPoint(obj.InvM, yzw(origin4));
-    newRay.dir = transformDirection(obj.InvM, yzw(dir4));
-    const float scale = length(newRay.dir);
-    newRay.dir = newRay.dir / scale;
+// ---- octree storage policies -------------------------------------------------------------------
+// Node<0>: the reference's 96-B nodes read field by field (a traversal step needs min/max,
+//          (trisIndex,trisCount), children[0], one children[k] and one neighbors[k], not the whole
+//          struct the reference copies).  Works for any valid octree.
+// Node<1>: the derived 64-B DNode + gathered DTri records (one dependent load per node, one per
+//          triangle).  Needs consecutive children, which the library checks at upload.
+typedef float v4f __attribute__((ext_vector_type(4)));   // native vectors: one 16-B load, SROA-friendly
+typedef int v4i __attribute__((ext_vector_type(4)));
+template <int V> struct NodeRef;
 
+template <> struct NodeRef<0> {
+    int idx;
+    RPT_DEV void load(const KernelArgs &a, int i) { idx = i; }
+    RPT_DEV f3 bmin(const KernelArgs &a) const { return ld3(a.octrees[idx].min); }
+    RPT_DEV f3 bmax(const KernelArgs &a) const { return ld3(a.octrees[idx].max); }
+    RPT_DEV bool is_leaf(const KernelArgs &a) const { return a.octrees[idx].children[0] == -1; }
+    RPT_DEV int child(const KernelArgs &a, int k) const { return a.octrees[idx].children[k]; }
+    RPT_DEV int neighbor(const KernelArgs &a, int side) const { return a.octrees[idx].neighbors[side]; }
+    RPT_DEV int tri_begin(const KernelArgs &a) const { return a.octrees[idx].trisIndex; }
+    RPT_DEV int tri_count(const KernelArgs &a) const { return a.octrees[idx].trisCount; }
+    // triangle k of the leaf: A, B-A, C-A and its id
+    RPT_DEV void tri(const KernelArgs &a, int k, f3 &A, f3 &v0v1, f3 &v0v2, int &id) const {
+        id = a.octreeTris[k];
+        A = ld3(a.vertices[a.triangles[9 * id + 3 * 0]]);
+        const f3 B = ld3(a.vertices[a.triangles[9 * id + 3 * 1]]);
+        const f3 C = ld3(a.vertices[a.triangles[9 * id + 3 * 2]]);
+        v0v1 = B - A;
+        v0v2 = C - A;
+    }
+};
+
+template <> struct NodeRef<1> {
+    // the 64-B record as four 16-B loads held in scalars (no struct copy: keeps it in registers)
+    v4f lo, hi;         // min.xyz | firstChild , max.xyz | leafBegin   (ints carried as float bits)
+    v4i q2, q3;         // leafCount, nb[0..2] , nb[3..5], pad
+    RPT_DEV void load(const KernelArgs &a, int i) {
+        const v4f *p = reinterpret_cast<const v4f *>(a.dnodes + i);
+        lo = p[0];
+        hi = p[1];
+        q2 = reinterpret_cast<const v4i *>(p)[2];
+        q3 = reinterpret_cast<const v4i *>(p)[3];
+    }
+    RPT_DEV f3 bmin(const KernelArgs &) const { return mk3(lo.x, lo.y, lo.z); }
+    RPT_DEV f3 bmax(const KernelArgs &) const { return mk3(hi.x, hi.y, hi.z); }
+    RPT_DEV int first_child() const { return __float_as_int(lo.w); }
+    RPT_DEV bool is_leaf(const KernelArgs &) const { return first_child() == -1; }
+    RPT_DEV int child(const KernelArgs &, int k) const { return first_child() + k; }
+    RPT_DEV int neighbor(const KernelArgs &, int side) const {   // select chain: no dynamic register indexing
+        int r = q2.y;
+        r = side == 1 ? q2.z : r;
+        r = side == 2 ? q2.w : r;
+        r = side == 3 ? q3.x : r;
+        r = side == 4 ? q3.y : r;
+        r = side == 5 ? q3.z : r;
+        return r;
+    }
+    RPT_DEV int tri_begin(const KernelArgs &) const { return __float_as_int(hi.w); }
+    RPT_DEV int tri_count(const KernelArgs &) const { return q2.x; }
+    RPT_DEV void tri(const KernelArgs &a, int k, f3 &A, f3 &v0v1, f3 &v0v2, int &id) const {
+        const v4f *p = reinterpret_cast<const v4f *>(a.dtris + k);
+        const v4f t0 = p[0], t1 = p[1], t2 = p[2];
+        A = mk3(t0.x, t0.y, t0.z);
+        v0v1 = mk3(t0.w, t1.x, t1.y);
+        v0v2 = mk3(t1.z, t1.w, t2.x);
+        id = __float_as_int(t2.y);
+    }
+};
+
+// opencl_kernel.cl:106-126 with the two edge vectors supplied
+RPT_DEV bool intersect_triangle_edges(f3 A, f3 v0v1, f3 v0v2, const Ray &ray, float &dist, f2 &uv) {
+    const f3 pvec = cross(ray.dir, v0v2);
+    const float det = dot(v0v1, pvec);
+    if (det < RPT_EPSILON && -RPT_EPSILON < det) return false;
+    const float invDet = 1 / det;
+    const f3 tvec = ray.origin - A;
+    uv.x = dot(tvec, pvec) * invDet;
+    if (uv.x < 0 || uv.x > 1) return false;
+    const f3 qvec = cross(tvec, v0v1);
+    uv.y = dot(ray.dir, qvec) * invDet;
+    if (uv.y < 0 || uv.x + uv.y > 1) return false;
+    dist = dot(v0v2, qvec) * invDet;
+    return true;
+}
+
+// opencl_kernel.cl:200-308 from the point where the ray is in object space.  newRay = object-space
+// ray (direction normalised); world_origin/world_dirlen are ray->origin.yzw and |ray->dir.yzw|.
+// Diagnostic counting (V == 2 only): how many loop iterations lanes need vs. how many the wave executes.
+template <int V>
+RPT_DEV void count_iter(const KernelArgs &a, int which) {
+    if (V == 2) {
+        const unsigned long long m = __ballot(1);
+        const int lane = threadIdx.x & 63;
+        if (lane == __ffsll((long long)m) - 1) {
+            atomicAdd(&a.counters[which], (unsigned long long)__popcll(m));
+            atomicAdd(&a.counters[3 + which], 1ull);
+        }
+    }
+}
+
+template <int V>
+RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &newRay, f3 world_origin,
+                         float world_dirlen, Hit &hit) {
+    NodeRef<(V == 0 ? 0 : 1)> node;
     int currOctreeIndex = obj.meshIndex;
+    node.load(a, currOctreeIndex);
     f2 d;
     int closeSide, farSide;
-    f3 nmin = ld3(octrees[currOctreeIndex].min), nmax = ld3(octrees[currOctreeIndex].max);
+    f3 nmin = node.bmin(a), nmax = node.bmax(a);
     if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
     f3 uv = newRay.origin + newRay.dir * d.x;
 
     if (d.x < 0) {   // ray starts inside the root: descend to the leaf holding the origin
         uv = (newRay.origin - nmin) / (nmax - nmin);
-        while (octrees[currOctreeIndex].children[0] != -1) {
+        while (!node.is_leaf(a)) {
             const int childIndex = octree_child_step(uv);
-            currOctreeIndex = octrees[currOctreeIndex].children[childIndex];
+            currOctreeIndex = node.child(a, childIndex);
+            node.load(a, currOctreeIndex);
         }
-        nmin = ld3(octrees[currOctreeIndex].min);
-        nmax = ld3(octrees[currOctreeIndex].max);
+        nmin = node.bmin(a);
+        nmax = node.bmax(a);
         if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
         uv = newRay.origin + newRay.dir * d.x;
     }
@@ -181,29 +303,33 @@ RPT_DEV bool intersect_octree(const KernelArgs &a, const rpt_object &obj, f4 ori
     int steps = 0;
     while (currOctreeIndex != -1) {
         if (++steps > RPT_MAX_LEAF_STEPS) break;
-        nmin = ld3(octrees[currOctreeIndex].min);
-        nmax = ld3(octrees[currOctreeIndex].max);
+        count_iter<V>(a, 0);
+        node.load(a, currOctreeIndex);
+        nmin = node.bmin(a);
+        nmax = node.bmax(a);
         uv = (uv - nmin) / (nmax - nmin);
         bool descended = false;
-        while (octrees[currOctreeIndex].children[0] != -1) {
+        while (!node.is_leaf(a)) {
             const int childIndex = octree_child_step(uv);
-            currOctreeIndex = octrees[currOctreeIndex].children[childIndex];
+            currOctreeIndex = node.child(a, childIndex);
+            node.load(a, currOctreeIndex);
             descended = true;
+            count_iter<V>(a, 2);
         }
         if (descended) {
-            nmin = ld3(octrees[currOctreeIndex].min);
-            nmax = ld3(octrees[currOctreeIndex].max);
+            nmin = node.bmin(a);
+            nmax = node.bmax(a);
         }
-        const int trisIndex = octrees[currOctreeIndex].trisIndex;
-        const int trisEnd = trisIndex + octrees[currOctreeIndex].trisCount;
+        const int trisIndex = node.tri_begin(a);
+        const int trisEnd = trisIndex + node.tri_count(a);
         for (int i = trisIndex; i < trisEnd; i++) {
-            const int tri = a.octreeTris[i];
-            const f3 A = ld3(a.vertices[a.triangles[9 * tri + 3 * 0]]);
-            const f3 B = ld3(a.vertices[a.triangles[9 * tri + 3 * 1]]);
-            const f3 C = ld3(a.vertices[a.triangles[9 * tri + 3 * 2]]);
+            f3 A, v0v1, v0v2;
+            int tri;
+            node.tri(a, i, A, v0v1, v0v2, tri);
+            count_iter<V>(a, 1);
             float dist;
             f2 triUV;
-            if (intersect_triangle(A, B, C, newRay, dist, triUV)) {
+            if (intersect_triangle_edges(A, v0v1, v0v2, newRay, dist, triUV)) {
                 if (0 <= dist && dist < hit.dist) {
                     hitTri = tri;
                     hit.dist = dist;
@@ -215,7 +341,7 @@ RPT_DEV bool intersect_octree(const KernelArgs &a, const rpt_object &obj, f4 ori
         const f3 extents = nmax - nmin;
         farSide = getOppositeBoxSide(plan, uv);
         uv = nmin + uv * extents;
-        currOctreeIndex = octrees[currOctreeIndex].neighbors[farSide];
+        currOctreeIndex = node.neighbor(a, farSide);
         if (length(uv - newRay.origin) > hit.dist) break;
     }
     if (!didHit) return false;
@@ -233,19 +359,17 @@ RPT_DEV bool intersect_octree(const KernelArgs &a, const rpt_object &obj, f4 ori
     hit.uv.y = w * uvA.y + u * uvB.y + v * uvC.y;
     const f3 objPoint = newRay.origin + newRay.dir * hit.dist;
     const f3 worldPoint = transformPoint(obj.M, objPoint);
-    hit.dist = length(worldPoint - yzw(origin4)) / length(yzw(dir4));
+    hit.dist = length(worldPoint - world_origin) / world_dirlen;
     return true;
 }
 
 RPT_DEV float max3(f3 v) { return cl_max(cl_max(v.x, v.y), v.z); }   // opencl_kernel.cl:310
+RPT_DEV float cube_winding(f3 origin) {
+    return max3(mk3(__builtin_fabsf(origin.x), __builtin_fabsf(origin.y), __builtin_fabsf(origin.z))) < 1.0f ? -1.0f : 1.0f;
+}
 
-// opencl_kernel.cl:312-333
-RPT_DEV bool intersect_cube(const rpt_object &obj, f4 origin4, f4 dir4, Hit &hit) {
-    const f3 origin = transformPoint(obj.InvM, yzw(origin4));
-    f3 dir = transformDirection(obj.InvM, yzw(dir4));
-    const float scale = length(dir);
-    dir = dir / scale;
-    const float winding = max3(mk3(__builtin_fabsf(origin.x), __builtin_fabsf(origin.y), __builtin_fabsf(origin.z))) < 1.0f ? -1.0f : 1.0f;
+// opencl_kernel.cl:312-333 from the object-space ray (dir normalised, scale = its former length)
+RPT_DEV bool cube_core(const rpt_object &obj, f3 origin, float winding, f3 dir, float scale, Hit &hit) {
     f3 sgn = mk3(-cl_sign(dir.x), -cl_sign(dir.y), -cl_sign(dir.z));
     const f3 d = (sgn * winding - origin) / dir;
 #define RPT_TEST(U, V, W) ((d.U >= 0.0f) && (__builtin_fabsf(origin.V + dir.V * d.U) < 1.0f) && (__builtin_fabsf(origin.W + dir.W * d.U) < 1.0f))
@@ -265,16 +389,12 @@ RPT_DEV bool intersect_cube(const rpt_object &obj, f4 origin4, f4 dir4, Hit &hit
     return true;
 }
 
-// opencl_kernel.cl:335-359.  The (u,v) of a sphere hit is only ever consumed by the texture
-// fetch, so it is evaluated only for textured spheres (want_uv); the double-precision divide by
-// M_PI is the reference's (M_PI is a double constant in OpenCL C).
-RPT_DEV bool intersect_sphere(const rpt_object &obj, f4 origin4, f4 dir4, Hit &hit, bool want_uv) {
-    const f3 rayToSphere = -transformPoint(obj.InvM, yzw(origin4));
-    f3 dir = transformDirection(obj.InvM, yzw(dir4));
-    const float scale = length(dir);
-    dir = dir / scale;
+// opencl_kernel.cl:335-359 from the object-space ray; c = dot(rayToSphere,rayToSphere) - 1.
+// The (u,v) of a sphere hit is only ever consumed by the texture fetch, so it is evaluated only
+// for textured spheres (want_uv); the double-precision divide by M_PI is the reference's (M_PI is a
+// double constant in OpenCL C).
+RPT_DEV bool sphere_core(const rpt_object &obj, f3 rayToSphere, float c, f3 dir, float scale, Hit &hit, bool want_uv) {
     const float b = dot(rayToSphere, dir);
-    const float c = dot(rayToSphere, rayToSphere) - 1.0f;
     float disc = b * b - c;
     if (disc < 0.0f) return false;
     disc = __builtin_sqrtf(disc);
@@ -295,13 +415,58 @@ RPT_DEV bool intersect_sphere(const rpt_object &obj, f4 origin4, f4 dir4, Hit &h
     return true;
 }
 
+// One object against one ray given as a 4-D event + 4-D direction in the object's rest frame
+// (the general form: shadow rays, and primary rays of the V = 0 kernel).
+template <int V>
 RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, Hit &hit) {
     const rpt_object &obj = a.objects[i];
+    const f3 origin = transformPoint(obj.InvM, yzw(origin4));
+    f3 dir = transformDirection(obj.InvM, yzw(dir4));
+    const float scale = length(dir);
+    dir = dir / scale;
     switch (obj.type) {
-    case RPT_SPHERE: return intersect_sphere(obj, origin4, dir4, hit, obj.textureIndex != -1);
-    case RPT_CUBE:   return intersect_cube(obj, origin4, dir4, hit);
-    case RPT_MESH:   return intersect_octree(a, obj, origin4, dir4, hit);
-    default:         return false;
+    case RPT_SPHERE: {
+        const f3 rayToSphere = -origin;
+        return sphere_core(obj, rayToSphere, dot(rayToSphere, rayToSphere) - 1.0f, dir, scale, hit, obj.textureIndex != -1);
+    }
+    case RPT_CUBE:
+        return cube_core(obj, origin, cube_winding(origin), dir, scale, hit);
+    case RPT_MESH: {
+        Ray newRay;
+        newRay.origin = origin;
+        newRay.dir = dir;
+        return octree_core<V>(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
+    }
+    default:
+        return false;
+    }
+}
+
+// Primary rays of the V >= 1 kernels: the object-space origin and what depends on it alone come
+// from the per-frame DObj record; only rows 1..3 of Lorentz * (interval, d) are formed (row 0, the
+// time component, is needed for the flash test of the final hit only).
+template <int V>
+RPT_DEV bool intersect_object_primary(const KernelArgs &a, int i, f4 rayDir, Hit &hit) {
+    const rpt_object &obj = a.objects[i];
+    const DObj &pre = a.dobjs[i];
+    const f3 d3 = mk3(dot(ld4(obj.Lorentz[1]), rayDir), dot(ld4(obj.Lorentz[2]), rayDir), dot(ld4(obj.Lorentz[3]), rayDir));
+    f3 dir = transformDirection(obj.InvM, d3);
+    const float scale = length(dir);
+    dir = dir / scale;
+    const f3 origin = mk3(pre.ox, pre.oy, pre.oz);
+    switch (obj.type) {
+    case RPT_SPHERE:
+        return sphere_core(obj, -origin, pre.sphere_c, dir, scale, hit, obj.textureIndex != -1);
+    case RPT_CUBE:
+        return cube_core(obj, origin, pre.winding, dir, scale, hit);
+    case RPT_MESH: {
+        Ray newRay;
+        newRay.origin = origin;
+        newRay.dir = dir;
+        return octree_core<V>(a, obj, newRay, mk3(obj.stationaryCam.y, obj.stationaryCam.z, obj.stationaryCam.w), length(d3), hit);
+    }
+    default:
+        return false;
     }
 }
 
@@ -341,6 +506,7 @@ RPT_DEV f3 sample_texture(const KernelArgs &a, const rpt_object &ho, f2 huv) {
 }
 
 // opencl_kernel.cl:488-545: true when something other than the light blocks the segment
+template <int V>
 RPT_DEV bool sample_light_occluded(const KernelArgs &a, f4 origin4, f4 dir4, float lightDist, int lightIndex) {
     const f3 nd = normalize(yzw(dir4));
     const f4 lightDir0 = mk4((float)a.interval, nd.x, nd.y, nd.z);
@@ -350,7 +516,7 @@ RPT_DEV bool sample_light_occluded(const KernelArgs &a, f4 origin4, f4 dir4, flo
             newHit.dist = 1e20f;
             const f4 newEvent0 = transformPoint4D(a.objects[i].Lorentz, origin4);
             const f4 lightDir = transformPoint4D(a.objects[i].Lorentz, lightDir0);
-            if (intersect_object(a, i, newEvent0, lightDir, newHit)) {
+            if (intersect_object<V>(a, i, newEvent0, lightDir, newHit)) {
                 if (newHit.dist < lightDist) return true;
             }
         }
@@ -359,36 +525,39 @@ RPT_DEV bool sample_light_occluded(const KernelArgs &a, f4 origin4, f4 dir4, flo
 }
 
 // opencl_kernel.cl:361-486 + 548-604: closest hit over the object list, surface colour, lights
-RPT_DEV f3 trace(const KernelArgs &a, f3 camdir) {
+// Returns false (and leaves `color` untouched) when the ray hits nothing: the caller then uses the
+// per-frame background constants instead of tonemapping (0.15,0.15,0.25) again for every pixel.
+template <int V>
+RPT_DEV bool trace(const KernelArgs &a, f3 camdir, f3 &color_out) {
     const float inf = 1e20f;
     Hit hit;
     hit.dist = inf;
     hit.object = -1;
-    f4 event = mk4(0, 0, 0, 0);
     const f3 nd = normalize(camdir);
     const f4 rayDir = mk4((float)a.interval, nd.x, nd.y, nd.z);
 
     for (int i = 0; i < a.object_count; i++) {
         Hit newHit;
         newHit.dist = inf;
-        const f4 newEvent0 = ld4(a.objects[i].stationaryCam);
-        const f4 lightDir = transformPoint4D(a.objects[i].Lorentz, rayDir);
-        if (intersect_object(a, i, newEvent0, lightDir, newHit)) {
+        bool got;
+        if (V == 0) got = intersect_object<0>(a, i, ld4(a.objects[i].stationaryCam), transformPoint4D(a.objects[i].Lorentz, rayDir), newHit);
+        else got = intersect_object_primary<V>(a, i, rayDir, newHit);
+        if (got) {
             if (newHit.dist < hit.dist) {
-                event = newEvent0 + lightDir * newHit.dist;
                 hit = newHit;
                 hit.object = i;
             }
         }
     }
-    if (hit.object < 0) return mk3(0.15f, 0.15f, 0.25f);
+    if (hit.object < 0) return false;
 
     const rpt_object &ho = a.objects[hit.object];
     f3 hcolor = ho.textureIndex != -1 ? sample_texture(a, ho, hit.uv) : ld3(ho.color);
-    if (ho.flashPeriod > 0) {   // proper-time flash, opencl_kernel.cl:476-482
+    if (ho.flashPeriod > 0) {   // proper-time flash, opencl_kernel.cl:476-482: event.x of the winning hit
+        const float event_x = ho.stationaryCam.x + dot(ld4(ho.Lorentz[0]), rayDir) * hit.dist;
         const float period = ho.flashPeriod;
         const float duration = ho.flashDuration;
-        if (event.x - period * __builtin_floorf(event.x / period) < duration) hcolor = hcolor * 2;
+        if (event_x - period * __builtin_floorf(event_x / period) < duration) hcolor = hcolor * 2;
     }
 
     f3 color = hcolor * (a.interval != 0 ? a.ambient : 1.0f);
@@ -415,7 +584,7 @@ RPT_DEV f3 trace(const KernelArgs &a, f3 camdir) {
                 if (ndotl > 0) {
                     const f3 ld = normalize(yzw(lightDir));
                     const f4 shadowDir = mk4((float)a.interval, ld.x, ld.y, ld.z);
-                    if (!sample_light_occluded(a, hitPos, shadowDir, length(yzw(lightDir)), i)) {
+                    if (!sample_light_occluded<V>(a, hitPos, shadowDir, length(yzw(lightDir)), i)) {
                         const float k = ndotl / (1.0f + 0.1f * length(lightDir3_ObjFrame) +
                                                  0.01f * dot(lightDir3_ObjFrame, lightDir3_ObjFrame));
                         color = color + hcolor * k * ld3(lo.color);
@@ -424,7 +593,8 @@ RPT_DEV f3 trace(const KernelArgs &a, f3 camdir) {
             }
         }
     }
-    return color;
+    color_out = color;
+    return true;
 }
 
 // opencl_kernel.cl:607-616
@@ -450,8 +620,11 @@ RPT_DEV uint32_t tonemap_pack(const KernelArgs &a, f3 color, f3 &mapped) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Variant 1: one thread per pixel, wave = 8x8 tile, workgroup = 32x8 strip.
-__global__ __launch_bounds__(256) void rpt_render_kernel(const KernelArgs a) {
+// One thread per pixel, wave = 8x8 tile, workgroup = 32x8 strip.
+//   V = 0: reads the reference layouts only (general fallback, any valid octree)
+//   V = 1: derived DNode/DTri/DObj layouts
+template <int V>
+RPT_DEV void render_pixel_body(const KernelArgs &a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int x_coord = blockIdx.x * 32 + wave * 8 + (lane & 7);
@@ -460,9 +633,10 @@ __global__ __launch_bounds__(256) void rpt_render_kernel(const KernelArgs a) {
     if (x_coord >= a.width || y_coord >= a.height) return;   // the reference has no guard (UB)
 
     const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);
-    const f3 color = trace(a, camdir);
-    f3 mapped;
-    const uint32_t packed = tonemap_pack(a, color, mapped);
+    f3 color;
+    f3 mapped = mk3(a.bg_mapped[0], a.bg_mapped[1], a.bg_mapped[2]);
+    uint32_t packed = a.bg_packed;
+    if (trace<V>(a, camdir, color)) packed = tonemap_pack(a, color, mapped);
 
     const size_t id = (size_t)y_coord * a.width + x_coord;
     if (a.out16) {
@@ -480,6 +654,14 @@ __global__ __launch_bounds__(256) void rpt_render_kernel(const KernelArgs a) {
         a.debug_rgb[3 * id + 2] = mapped.z;
     }
 }
+
+__global__ __launch_bounds__(256) void rpt_render_kernel_v0(const KernelArgs a) { render_pixel_body<0>(a); }
+__global__ __launch_bounds__(256) void rpt_render_kernel_v1(const KernelArgs a) { render_pixel_body<1>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_w4(const KernelArgs a) { render_pixel_body<1>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_v1_w5(const KernelArgs a) { render_pixel_body<1>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_v1_w6(const KernelArgs a) { render_pixel_body<1>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_v1_w8(const KernelArgs a) { render_pixel_body<1>(a); }
+__global__ __launch_bounds__(256) void rpt_render_kernel_v1_diag(const KernelArgs a) { render_pixel_body<2>(a); }
 
 // Root-side reassembly after the gather: plane of rank r, local tile k -> global tile r + k*n_ranks.
 __global__ __launch_bounds__(256) void rpt_scatter_plane_kernel(const uint32_t *planes, rpt_pixel *out16, int width,

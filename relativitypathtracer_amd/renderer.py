@@ -146,6 +146,11 @@ class Renderer:
                                                        height, n_ranks, plane_stride_words, 0),
                     "rpt_scatter_colour_plane")
 
+    def read_counters(self):
+        out = (C.c_uint64 * 8)()
+        self._check(self._lib.rpt_read_counters(self._h, out), "rpt_read_counters")
+        return list(out)
+
     def probe(self, which: int, inputs: np.ndarray, out_width: int) -> np.ndarray:
         inputs = np.ascontiguousarray(inputs, dtype=np.float32)
         n = inputs.shape[0]

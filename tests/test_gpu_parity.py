@@ -25,7 +25,8 @@ def renderer():
     r.close()
 
 
-def _render_gpu(r, scene, W, H):
+def _render_gpu(r, scene, W, H, variant=0):
+    r.set_variant(variant)
     r.upload_scene(scene)
     r.set_scene_params(scene, W, H)
     r.set_rows(0, 1, False)
@@ -40,11 +41,15 @@ SIZES = {"cube": (640, 480), "arch": (480, 270), "arch_t0": (480, 270), "bunny":
 EXACT = {"cube", "arch", "arch_t0", "bunny", "shadows", "cubes", "rulers", "ladder"}
 
 
+VARIANTS = [0, 1, 2, 3, 4, 5, 6]   # 0 = default; 1 = reference-layout kernel; 2.. = derived-layout kernels
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("name", list(SIZES))
-def test_frame_matches_oracle(renderer, name):
+def test_frame_matches_oracle(renderer, name, variant):
     W, H = SIZES[name]
     scene = load_config(name)
-    px, rgb = _render_gpu(renderer, scene, W, H)
+    px, rgb = _render_gpu(renderer, scene, W, H, variant)
     opx, orgb, _ = oracle_ffi.render(scene, W, H)
     assert np.array_equal(px["x"], opx["x"]) and np.array_equal(px["y"], opx["y"])
     assert np.all(px["rgba"][:, 3] == 1)
