@@ -1,0 +1,107 @@
+"""Known-answer tests of single device functions (rpt_probe) against the oracle's per-function entry
+points, on random and edge-case inputs: bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_ffi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    from relativitypathtracer_amd.renderer import Renderer
+    r = Renderer(0)
+    yield r
+    r.close()
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def test_intersect_triangle(renderer):
+    rng = np.random.default_rng(7)
+    n = 4096
+    tri = rng.uniform(-2, 2, size=(n, 9)).astype(np.float32)
+    org = rng.uniform(-3, 3, size=(n, 3)).astype(np.float32)
+    # aim most rays at a random point of their triangle so that a good share hits
+    w = rng.dirichlet((1, 1, 1), size=n).astype(np.float32)
+    target = (tri.reshape(n, 3, 3) * w[:, :, None]).sum(axis=1)
+    d = target - org + rng.normal(0, 0.05, size=(n, 3)).astype(np.float32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    # edge cases: ray in the triangle's plane, degenerate triangle, axis-parallel rays, ray through a vertex
+    tri[0] = [0, 0, 0, 1, 0, 0, 0, 1, 0]; org[0] = [-1, 0.2, 0]; d[0] = [1, 0, 0]
+    tri[1] = [1, 1, 1, 1, 1, 1, 2, 2, 2]
+    tri[2] = [0, 0, 1, 1, 0, 1, 0, 1, 1]; org[2] = [0, 0, 0]; d[2] = [0, 0, 1]
+    tri[3] = [0, 0, 1, 1, 0, 1, 0, 1, 1]; org[3] = [0.25, 0.25, 0]; d[3] = [0, 0, 1]
+    tri[4] = [0, 0, 1, 1, 0, 1, 0, 1, 1]; org[4] = [0.25, 0.25, 2]; d[4] = [0, 0, 1]     # behind the origin: negative dist
+    inp = np.concatenate([tri, org, d], axis=1)
+    got = renderer.probe(0, inp, 4)
+    lib = oracle_ffi.lib()
+    want = np.zeros((n, 4), np.float32)
+    for i in range(n):
+        o3 = np.zeros(3, np.float32)
+        h = lib.rpt_oracle_tri(_fp(tri[i, 0:3].copy()), _fp(tri[i, 3:6].copy()), _fp(tri[i, 6:9].copy()), _fp(org[i].copy()), _fp(d[i].copy()), _fp(o3))
+        want[i] = [h, *o3]
+    assert want[:, 0].sum() > n // 4
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_intersect_aabb(renderer):
+    rng = np.random.default_rng(11)
+    n = 4096
+    lo = rng.uniform(-2, 0, size=(n, 3)).astype(np.float32)
+    hi = (lo + rng.uniform(0.1, 3, size=(n, 3))).astype(np.float32)
+    org = rng.uniform(-4, 4, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    org[:200] = ((lo[:200] + hi[:200]) / 2).astype(np.float32)          # origin inside the box
+    d[200:260] = [1, 0, 0]; d[260:320] = [0, -1, 0]; d[320:380] = [0, 0, 1]    # axis-parallel: 1/0 = inf, 0*inf = NaN
+    d[380:400, 0] = -0.0
+    org[400:420, 0] = lo[400:420, 0]                                     # origin exactly on a face plane
+    inp = np.concatenate([lo, hi, org, d], axis=1)
+    got = renderer.probe(1, inp, 5)
+    lib = oracle_ffi.lib()
+    want = np.zeros((n, 5), np.float32)
+    for i in range(n):
+        d2 = np.zeros(2, np.float32); s2 = (C.c_int * 2)()
+        h = lib.rpt_oracle_aabb(_fp(lo[i].copy()), _fp(hi[i].copy()), _fp(org[i].copy()), _fp(d[i].copy()), _fp(d2), s2)
+        want[i] = [h, d2[0], d2[1], s2[0], s2[1]]
+    assert 0.2 < want[:, 0].mean() < 0.9
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_camera_ray_every_column_and_row(renderer):
+    lib = oracle_ffi.lib()
+    cases = []
+    for (W, H) in [(640, 480), (1920, 1080), (3840, 2160), (7680, 4320), (333, 77)]:
+        xs = np.unique(np.concatenate([np.arange(0, W, max(W // 97, 1)), [W - 1]]))
+        ys = np.unique(np.concatenate([np.arange(0, H, max(H // 89, 1)), [H - 1]]))
+        for x in xs:
+            for y in ys[:: max(len(ys) // 9, 1)]:
+                cases.append((x, y, W, H))
+    inp = np.array(cases, np.float32)
+    got = renderer.probe(2, inp, 3)
+    want = np.zeros_like(got)
+    o = np.zeros(3, np.float32)
+    for i, (x, y, W, H) in enumerate(cases):
+        lib.rpt_oracle_camray(float(x), float(y), int(W), int(H), _fp(o))
+        want[i] = o
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_hable(renderer):
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(0, 30, size=(3000, 3)), rng.uniform(0, 1e-3, size=(500, 3)),
+                        np.array([[0, 0, 0], [1, 1, 1], [0.15, 0.15, 0.25], [10, 10, 10], [2, 2, 2], [1e20, 1e-30, 5]])]).astype(np.float32)
+    got = renderer.probe(3, x, 3)
+    lib = oracle_ffi.lib()
+    want = np.zeros_like(got)
+    o = np.zeros(3, np.float32)
+    for i in range(len(x)):
+        lib.rpt_oracle_hable(_fp(x[i].copy()), _fp(o))
+        want[i] = o
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

@@ -1,0 +1,227 @@
+"""HIP path at BASELINE.json's full sizes through size-independent properties, against committed
+golden frames, and the boundary's error behaviour.  All comparisons bit-exact unless stated."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi
+from conftest import CONFIGS, load_config
+from relativitypathtracer_amd import dist as rdist
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    from relativitypathtracer_amd.renderer import Renderer
+    r = Renderer(0)
+    yield r
+    r.close()
+
+
+def _setup(r, scene, W, H, variant=0):
+    r.set_variant(variant)
+    r.upload_scene(scene)
+    r.set_scene_params(scene, W, H)
+    r.set_rows(0, 1, False)
+    r.set_plane_output(None)
+    r.set_output(None)
+    r.set_debug_rgb(False)
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_against_committed_golden_frames(renderer, name):
+    g = np.load(os.path.join(GOLDEN, f"oracle_{name}_128x72.npz"))
+    scene = load_config(name)
+    _setup(renderer, scene, 128, 72)
+    renderer.set_debug_rgb(True)
+    renderer.render()
+    px, rgb = renderer.read_framebuffer(), renderer.read_debug_rgb()
+    assert np.abs(rgb - g["rgb"]).max() <= 1e-4
+    if name != "soccer":
+        assert np.array_equal(px["rgba"].reshape(72, 128, 4), g["rgba"])
+        assert np.array_equal(rgb.view(np.uint32), g["rgb"].view(np.uint32))
+
+
+FULL = [("bunny", 3840, 2160), ("shadows", 3840, 2160), ("arch", 1920, 1080), ("bunny", 7680, 4320)]
+
+
+@pytest.mark.parametrize("name,W,H", FULL)
+def test_full_size_rows_match_oracle(renderer, name, W, H):
+    """Full-resolution frame; the oracle renders only a few row bands (it is the slow side)."""
+    scene = load_config(name)
+    _setup(renderer, scene, W, H)
+    renderer.set_debug_rgb(True)
+    renderer.render()
+    px = renderer.read_framebuffer().reshape(H, W)
+    rgb = renderer.read_debug_rgb()
+    assert np.array_equal(px["x"][H // 3], np.arange(W, dtype=np.float32))
+    assert np.array_equal(px["y"][:, W // 2], np.arange(H, dtype=np.float32))
+    assert np.all(px["rgba"][..., 3] == 1) and not px["unspecified"].any()
+    bands = [(0, 8), (H * 2 // 5, H * 2 // 5 + 24), (H // 2 - 4, H // 2 + 12), (H - 8, H)]
+    for (r0, r1) in bands:
+        opx, orgb, _ = oracle_ffi.render(scene, W, H, rows=(r0, r1))
+        assert np.array_equal(px["rgba"][r0:r1], opx["rgba"].reshape(H, W, 4)[r0:r1]), f"{name} rows {r0}:{r1}"
+        assert np.array_equal(rgb[r0:r1].view(np.uint32), orgb[r0:r1].view(np.uint32))
+
+
+def test_render_is_idempotent_and_variants_agree(renderer):
+    scene = load_config("bunny")
+    W, H = 3840, 2160
+    frames = []
+    for variant in (0, 0, 1, 2, 3):
+        _setup(renderer, scene, W, H, variant)
+        renderer.render()
+        frames.append(renderer.read_framebuffer())
+    for f in frames[1:]:
+        assert np.array_equal(f.view(np.uint8), frames[0].view(np.uint8))
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_row_tile_shards_reassemble_to_the_single_gpu_frame(renderer, world):
+    """N-GPU frame == 1-GPU frame with the N ranks run one after another on this GPU:
+    colour planes from rpt_set_rows(rank, N, plane) + rpt_scatter_colour_plane vs a plain render."""
+    import torch
+    scene = load_config("shadows")
+    W, H = 1920, 1080
+    _setup(renderer, scene, W, H)
+    renderer.render()
+    want = renderer.read_framebuffer()
+    words = rdist.plane_words(W, H, world)
+    gathered = torch.zeros((world, words), dtype=torch.int32, device="cuda")
+    for rank in range(world):
+        renderer.set_rows(rank, world, True)
+        renderer.set_plane_output(gathered[rank].data_ptr())
+        renderer.render()
+        host_plane = renderer.read_colour_plane()
+        assert host_plane.shape == (rdist.local_tile_count(H, rank, world) * 8, W)
+    torch.cuda.synchronize()
+    out = torch.zeros(W * H * 4, dtype=torch.int32, device="cuda")
+    renderer.scatter_colour_plane(gathered.data_ptr(), out.data_ptr(), W, H, world, words)
+    renderer.sync()
+    got = out.cpu().numpy().view(want.dtype)
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    # and the host restatement of the scatter agrees with the kernel
+    host = rdist.reassemble_planes(gathered.cpu().numpy().view(np.uint32), W, H, world)
+    assert np.array_equal(host.view(np.uint8), want.view(np.uint8))
+    renderer.set_rows(0, 1, False)
+    renderer.set_plane_output(None)
+
+
+def test_external_output_buffer_and_stream(renderer):
+    import torch
+    scene = load_config("cube")
+    W, H = 640, 480
+    _setup(renderer, scene, W, H)
+    renderer.render()
+    want = renderer.read_framebuffer()
+    buf = torch.zeros(W * H * 4, dtype=torch.int32, device="cuda")
+    s = torch.cuda.Stream()
+    renderer.set_stream(s.cuda_stream)
+    renderer.set_output(buf.data_ptr())
+    renderer.render_async()
+    s.synchronize()
+    assert np.array_equal(buf.cpu().numpy().view(np.uint8), want.view(np.uint8))
+    renderer.set_stream(None)
+    renderer.set_output(None)
+    assert renderer.last_frame_ms() > 0
+
+
+def test_objects_refresh_changes_the_frame(renderer):
+    """rpt_set_objects is the per-frame call: moving the camera clock must move a 0.95c light's shadows."""
+    scene = load_config("shadows")
+    W, H = 480, 270
+    _setup(renderer, scene, W, H)
+    renderer.render()
+    a = renderer.read_framebuffer()
+    scene.set_camera((0, 0, 0), 17.0)
+    scene.update_objects()
+    renderer.set_objects(scene)
+    renderer.render()
+    b = renderer.read_framebuffer()
+    assert not np.array_equal(a["rgba"], b["rgba"])
+    opx, _, _ = oracle_ffi.render(scene, W, H, want_rgb=False)
+    assert np.array_equal(b["rgba"], opx["rgba"])
+
+
+def test_empty_scene_and_zero_objects(renderer):
+    from relativitypathtracer_amd import Scene
+    s = Scene()
+    s.inputScene("A0.2\nR\n")
+    _setup(renderer, s, 100, 60)
+    renderer.render()
+    px = renderer.read_framebuffer()
+    assert np.all(px["rgba"] == np.array([47, 47, 76, 1], np.uint8))
+
+
+def test_invalid_scenes_are_rejected_before_launch(renderer):
+    from relativitypathtracer_amd import _ffi
+    from relativitypathtracer_amd.renderer import RenderError
+    scene = load_config("shadows")
+    b = scene.buffers()
+    d = scene.desc()
+
+    def desc_with(**over):
+        keep = {k: np.ascontiguousarray(v).copy() for k, v in b.items()}
+        keep.update(over)
+        dd = _ffi.SceneDesc()
+        dd.objects, dd.object_count = keep["objects"].ctypes.data, keep["objects"].size // 320
+        dd.vertices, dd.vertex_count = keep["vertices"].ctypes.data, len(keep["vertices"])
+        dd.normals, dd.normal_count = keep["normals"].ctypes.data, len(keep["normals"])
+        dd.uvs, dd.uv_count = keep["uvs"].ctypes.data, len(keep["uvs"])
+        dd.triangles, dd.triangle_words = keep["triangles"].ctypes.data, keep["triangles"].size
+        dd.octrees, dd.octree_count = keep["octrees"].ctypes.data, keep["octrees"].size // 96
+        dd.octreeTris, dd.octree_tri_count = keep["octreeTris"].ctypes.data, keep["octreeTris"].size
+        dd.textures, dd.texture_bytes = (keep["textures"].ctypes.data if keep["textures"].size else None), keep["textures"].size
+        return dd, keep
+
+    tri = b["triangles"].copy(); tri[9] = 10 ** 6
+    with pytest.raises(RenderError, match="vertex index"):
+        renderer.upload_desc(desc_with(triangles=tri)[0])
+    ot = b["octreeTris"].copy(); ot[5] = -3
+    with pytest.raises(RenderError, match="octreeTris"):
+        renderer.upload_desc(desc_with(octreeTris=ot)[0])
+    oc = b["octrees"].copy().view(np.int32).reshape(-1, 24); oc[0, 10] = 10 ** 7     # children[0] of the root
+    with pytest.raises(RenderError, match="child index"):
+        renderer.upload_desc(desc_with(octrees=oc.view(np.uint8).reshape(-1))[0])
+    ob = b["objects"].copy().view(np.int32).reshape(-1, 80); ob[4, 73] = 10 ** 6       # meshIndex of the mesh object
+    with pytest.raises(RenderError, match="meshIndex"):
+        renderer.upload_desc(desc_with(objects=ob.view(np.uint8).reshape(-1))[0])
+    ob = b["objects"].copy().view(np.int32).reshape(-1, 80); ob[1, 74] = 0; ob[1, 75] = 64; ob[1, 76] = 64   # texture on an empty pool
+    with pytest.raises(RenderError, match="texture"):
+        renderer.upload_desc(desc_with(objects=ob.view(np.uint8).reshape(-1))[0])
+    # a general octree whose children are not consecutive takes the reference-layout kernel and still matches
+    renderer.upload_scene(scene)
+    assert d.object_count == 5
+
+
+def test_non_consecutive_children_fall_back_to_general_kernel(renderer):
+    """Swap two sibling subtrees' slots: a valid octree the derived layout cannot express."""
+    scene = load_config("shadows")
+    b = scene.buffers()
+    W, H = 320, 184
+    oc = b["octrees"].copy().view(np.int32).reshape(-1, 24)
+    root = scene.mesh_roots()[0]
+    kids = oc[root, 10:18].copy()
+    # permute the child table AND relabel consistently: swapping the node records of child 0 and child 1
+    # keeps geometry identical only if we also swap their indices in the parent; instead simply append a copy
+    # of child 0's record at the end and point the parent at it (children no longer consecutive).
+    new = np.vstack([oc, oc[kids[0]][None]])
+    new[root, 10] = len(oc)
+    # neighbours that pointed to the old child 0 keep pointing to it: it is an identical record, results are equal
+    from relativitypathtracer_amd import _ffi
+    dd = scene.desc()
+    d2 = _ffi.SceneDesc.from_buffer_copy(dd)
+    raw = np.ascontiguousarray(new).view(np.uint8).reshape(-1)
+    d2.octrees, d2.octree_count = raw.ctypes.data, len(new)
+    renderer.set_variant(0)
+    renderer.upload_desc(d2)
+    renderer.set_scene_params(scene, W, H)
+    renderer.set_rows(0, 1, False); renderer.set_output(None)
+    renderer.render()
+    got = renderer.read_framebuffer()
+    opx, _, _ = oracle_ffi.render(scene, W, H, want_rgb=False)
+    assert np.array_equal(got["rgba"], opx["rgba"])
