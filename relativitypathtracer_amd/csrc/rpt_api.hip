@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rpt.h"
@@ -133,10 +134,33 @@ int validate_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
             return fail(ctx, RPT_ERR_SCENE, "octree: triangle range out of bounds");
         for (int c = 0; c < 8; c++) {
             if (n.children[c] < -1 || n.children[c] >= n_nodes) return fail(ctx, RPT_ERR_SCENE, "octree: child index out of range");
-            if (n.children[0] != -1 && (n.children[c] <= (long long)i)) return fail(ctx, RPT_ERR_SCENE, "octree: child index does not increase (descent would not terminate)");
+            if (n.children[0] != -1 && n.children[c] == -1) return fail(ctx, RPT_ERR_SCENE, "octree: interior node with a missing child");
         }
         for (int c = 0; c < 6; c++)
             if (n.neighbors[c] < -1 || n.neighbors[c] >= n_nodes) return fail(ctx, RPT_ERR_SCENE, "octree: neighbour index out of range");
+    }
+    // the child links must form a forest (no cycles), or the descent loops would not terminate
+    std::vector<uint8_t> state(s.octree_count, 0);   // 0 unvisited, 1 on the DFS stack, 2 done
+    std::vector<std::pair<int, int>> stack;
+    for (size_t r = 0; r < s.octree_count; r++) {
+        if (state[r]) continue;
+        stack.push_back({(int)r, 0});
+        state[r] = 1;
+        while (!stack.empty()) {
+            auto &top = stack.back();
+            const rpt_octree &n = s.octrees[top.first];
+            if (n.children[0] == -1 || top.second == 8) {
+                state[top.first] = 2;
+                stack.pop_back();
+                continue;
+            }
+            const int c = n.children[top.second++];
+            if (state[c] == 1) return fail(ctx, RPT_ERR_SCENE, "octree: child links form a cycle");
+            if (state[c] == 0) {
+                state[c] = 1;
+                stack.push_back({c, 0});
+            }
+        }
     }
     return RPT_OK;
 }

@@ -57,6 +57,8 @@ def test_intersect_aabb(renderer):
     hi = (lo + rng.uniform(0.1, 3, size=(n, 3))).astype(np.float32)
     org = rng.uniform(-4, 4, size=(n, 3)).astype(np.float32)
     d = rng.normal(size=(n, 3)).astype(np.float32)
+    aim = ((lo + hi) / 2 - org + rng.normal(0, 0.8, size=(n, 3))).astype(np.float32)
+    d[: n // 2] = aim[: n // 2]                                          # half the rays aimed near the box
     d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     org[:200] = ((lo[:200] + hi[:200]) / 2).astype(np.float32)          # origin inside the box
     d[200:260] = [1, 0, 0]; d[260:320] = [0, -1, 0]; d[320:380] = [0, 0, 1]    # axis-parallel: 1/0 = inf, 0*inf = NaN

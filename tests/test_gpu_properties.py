@@ -180,20 +180,23 @@ def test_invalid_scenes_are_rejected_before_launch(renderer):
 
     tri = b["triangles"].copy(); tri[9] = 10 ** 6
     with pytest.raises(RenderError, match="vertex index"):
-        renderer.upload_desc(desc_with(triangles=tri)[0])
+        dd, _keep = desc_with(triangles=tri); renderer.upload_desc(dd)
     ot = b["octreeTris"].copy(); ot[5] = -3
     with pytest.raises(RenderError, match="octreeTris"):
-        renderer.upload_desc(desc_with(octreeTris=ot)[0])
+        dd, _keep = desc_with(octreeTris=ot); renderer.upload_desc(dd)
     oc = b["octrees"].copy().view(np.int32).reshape(-1, 24); oc[0, 10] = 10 ** 7     # children[0] of the root
     with pytest.raises(RenderError, match="child index"):
-        renderer.upload_desc(desc_with(octrees=oc.view(np.uint8).reshape(-1))[0])
+        dd, _keep = desc_with(octrees=oc.view(np.uint8).reshape(-1)); renderer.upload_desc(dd)
     ob = b["objects"].copy().view(np.int32).reshape(-1, 80); ob[4, 73] = 10 ** 6       # meshIndex of the mesh object
     with pytest.raises(RenderError, match="meshIndex"):
-        renderer.upload_desc(desc_with(objects=ob.view(np.uint8).reshape(-1))[0])
+        dd, _keep = desc_with(objects=ob.view(np.uint8).reshape(-1)); renderer.upload_desc(dd)
     ob = b["objects"].copy().view(np.int32).reshape(-1, 80); ob[1, 74] = 0; ob[1, 75] = 64; ob[1, 76] = 64   # texture on an empty pool
     with pytest.raises(RenderError, match="texture"):
-        renderer.upload_desc(desc_with(objects=ob.view(np.uint8).reshape(-1))[0])
-    # a general octree whose children are not consecutive takes the reference-layout kernel and still matches
+        dd, _keep = desc_with(objects=ob.view(np.uint8).reshape(-1)); renderer.upload_desc(dd)
+    oc = b["octrees"].copy().view(np.int32).reshape(-1, 24); oc[9, 10:18] = 0            # a node whose children point back at the root
+    oc[9, 10:18] = np.arange(8) * 0 + int(scene.mesh_roots()[0])
+    with pytest.raises(RenderError, match="cycle"):
+        dd, _keep = desc_with(octrees=oc.view(np.uint8).reshape(-1)); renderer.upload_desc(dd)
     renderer.upload_scene(scene)
     assert d.object_count == 5
 
