@@ -56,6 +56,8 @@ def cpu_baseline(scene, width, height, budget_s=12.0):
         threads = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    # the GPU box gives one GPU's share of the host: 16 cores (more threads than that only fight each other)
+    threads = max(1, min(threads, int(os.environ.get("RPT_CPU_THREADS", "16"))))
     oracle_ffi.render(scene, width, min(height, 64), want_rgb=False, threads=threads)   # page in
     frames, t0 = 0, time.perf_counter()
     while True:
