@@ -121,6 +121,10 @@ int rpt_scatter_colour_plane(rpt_ctx *ctx, const void *planes, void *out16, int 
  * once per executing wavefront (lane sum / (64 * wave count) = SIMD utilisation of that loop). */
 int rpt_read_counters(rpt_ctx *ctx, unsigned long long out[8]);
 
+/* Diagnostic variant 7 only: per-wavefront {start, end} stamps (100 MHz s_memrealtime) of the last
+ * frame, wave w = (blockIdx.y*gridDim.x + blockIdx.x)*4 + wave-in-block. */
+int rpt_read_wave_times(rpt_ctx *ctx, unsigned long long *out, size_t max_words, size_t *words);
+
 /* Known-answer probes of individual device functions (tests): which = 0 intersect_triangle
  * (in 15 floats -> out 4), 1 intersect_AABB (12 -> 5), 2 createCamRay (4 -> 3), 3 hable (3 -> 3). */
 int rpt_probe(rpt_ctx *ctx, int which, const void *host_in, void *host_out, int n);

@@ -141,6 +141,7 @@ HIP_SYMBOLS = {
     "rpt_timing_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "rpt_timing_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "rpt_read_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rpt_read_wave_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rpt_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "rpt_version": (C.c_char_p, []),
 }

@@ -33,7 +33,10 @@ struct rpt_ctx {
     std::string error;
 
     DeviceBuffer objects, vertices, normals, uvs, triangles, octrees, octreeTris, textures;
-    DeviceBuffer counters;
+    DeviceBuffer counters, wave_times;
+    DeviceBuffer tile_masks, bin_counts, bin_lists;   // tile binning (variant 12)
+    std::vector<uint8_t> host_objects;                // last Object[] (DObj depends on `interval`: rebuilt when it changes)
+    std::vector<float> host_node_bounds;              // min.xyz,max.xyz per octree node (culling spheres of mesh roots)
     DeviceBuffer dnodes, dtris, dobjs;        // derived layouts (rpt_kernels.hip.h)
     bool compact_ok = false;                  // derived octree layout usable (children consecutive)
     DeviceBuffer owned_out, owned_plane, owned_rgb;
@@ -216,7 +219,7 @@ int build_derived_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
 
 // Per-frame DObj records: the primary-ray origin in each object's space and what follows from it
 // (opencl_kernel.cl:314,318 / 336,341), with the kernel's operation order.
-void build_dobjs(const rpt_object *objs, int count, rptd::DObj *out) {
+void build_dobjs(const rpt_ctx *ctx, const rpt_object *objs, int count, rptd::DObj *out) {
     for (int i = 0; i < count; i++) {
         const rpt_object &o = objs[i];
         const float vx = o.stationaryCam.y, vy = o.stationaryCam.z, vz = o.stationaryCam.w;
@@ -231,6 +234,31 @@ void build_dobjs(const rpt_object *objs, int count, rptd::DObj *out) {
         const float m1 = ax < ay ? ay : ax;
         const float m2 = m1 < az ? az : m1;
         d.winding = m2 < 1.0f ? -1.0f : 1.0f;
+        // ---- culling data (approximate on purpose; see rpt_tile_bin_kernel) ----
+        // object-space direction of a primary ray with camera direction nd: InvM3 * (interval * L[1..3][0] + L[1..3][1..3] * nd)
+        const float interval = (float)ctx->interval;
+        bool finite = true;
+        for (int r = 0; r < 3; r++) {
+            const float m[3] = {o.InvM[r].x, o.InvM[r].y, o.InvM[r].z};
+            for (int c = 0; c < 3; c++) {
+                const float lc[3] = {(&o.Lorentz[1].x)[c + 1], (&o.Lorentz[2].x)[c + 1], (&o.Lorentz[3].x)[c + 1]};
+                d.B[3 * r + c] = m[0] * lc[0] + m[1] * lc[1] + m[2] * lc[2];
+                finite = finite && std::isfinite(d.B[3 * r + c]);
+            }
+            d.b[r] = interval * (m[0] * o.Lorentz[1].x + m[1] * o.Lorentz[2].x + m[2] * o.Lorentz[3].x);
+            finite = finite && std::isfinite(d.b[r]) && std::isfinite(p[r]);
+        }
+        d.cbx = d.cby = d.cbz = 0.0f;
+        float radius = -1.0f;
+        if (o.type == RPT_SPHERE) radius = 1.0f;
+        else if (o.type == RPT_CUBE) radius = 1.7320508f;
+        else if (o.type == RPT_MESH && (size_t)o.meshIndex * 6 + 5 < ctx->host_node_bounds.size()) {
+            const float *nb = &ctx->host_node_bounds[(size_t)o.meshIndex * 6];
+            d.cbx = 0.5f * (nb[0] + nb[3]); d.cby = 0.5f * (nb[1] + nb[4]); d.cbz = 0.5f * (nb[2] + nb[5]);
+            const float ex = nb[3] - nb[0], ey = nb[4] - nb[1], ez = nb[5] - nb[2];
+            radius = 0.5f * std::sqrt(ex * ex + ey * ey + ez * ez);
+        }
+        d.rb = (finite && radius >= 0.0f && std::isfinite(radius)) ? radius * 1.02f + 1.0e-5f : -1.0f;
         out[i] = d;
     }
 }
@@ -336,6 +364,34 @@ int launch(rpt_ctx *ctx) {
         a.counters = (unsigned long long *)ctx->counters.ptr;
         hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_diag, grid, dim3(256), 0, ctx->stream, a);
         break;
+    case 11:
+        if (int rc = reserve(ctx, ctx->wave_times, (size_t)grid.x * grid.y * 4 * 2 * sizeof(unsigned long long))) return rc;
+        RPT_HIP(ctx, hipMemsetAsync(ctx->wave_times.ptr, 0, ctx->wave_times.bytes, ctx->stream));
+        a.wave_times = (unsigned long long *)ctx->wave_times.ptr;
+        hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_timeline, grid, dim3(256), 0, ctx->stream, a);
+        break;
+    case 12: {
+        const int tiles_x = (ctx->width + 7) / 8;
+        const int n_tiles = tiles_x * tiles;
+        if (int rc = reserve(ctx, ctx->tile_masks, (size_t)n_tiles * 8)) return rc;
+        if (int rc = reserve(ctx, ctx->bin_counts, 16)) return rc;
+        if (int rc = reserve(ctx, ctx->bin_lists, (size_t)n_tiles * 3 * 4)) return rc;
+        a.tiles_x = tiles_x;
+        a.n_tiles = n_tiles;
+        a.tile_masks = (unsigned long long *)ctx->tile_masks.ptr;
+        a.bin_counts = (unsigned int *)ctx->bin_counts.ptr;
+        a.bin_lists = (unsigned int *)ctx->bin_lists.ptr;
+        a.mesh_object_bits = 0;
+        for (int i = 0; i < ctx->object_count && i < 64; i++)
+            if (((const rpt_object *)ctx->host_objects.data())[i].type == RPT_MESH) a.mesh_object_bits |= 1ull << i;
+        RPT_HIP(ctx, hipMemsetAsync(ctx->bin_counts.ptr, 0, 16, ctx->stream));
+        hipLaunchKernelGGL(rptd::rpt_tile_bin_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(rptd::rpt_render_binned_v1, dim3((n_tiles + 3) / 4), dim3(256), 0, ctx->stream, a);
+        break;
+    }
+    case 8: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only, grid, dim3(256), 0, ctx->stream, a); break;
+    case 9: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only_w6, grid, dim3(256), 0, ctx->stream, a); break;
+    case 10: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only_w8, grid, dim3(256), 0, ctx->stream, a); break;
     default: return fail(ctx, RPT_ERR_ARG, "unknown kernel variant");
     }
     RPT_HIP(ctx, hipGetLastError());
@@ -372,7 +428,7 @@ void rpt_destroy(rpt_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     for (DeviceBuffer *b : {&ctx->objects, &ctx->vertices, &ctx->normals, &ctx->uvs, &ctx->triangles, &ctx->octrees,
-                            &ctx->octreeTris, &ctx->textures, &ctx->dnodes, &ctx->dtris, &ctx->dobjs, &ctx->counters, &ctx->owned_out, &ctx->owned_plane, &ctx->owned_rgb})
+                            &ctx->octreeTris, &ctx->textures, &ctx->dnodes, &ctx->dtris, &ctx->dobjs, &ctx->counters, &ctx->wave_times, &ctx->tile_masks, &ctx->bin_counts, &ctx->bin_lists, &ctx->owned_out, &ctx->owned_plane, &ctx->owned_rgb})
         release(*b);
     if (ctx->pinned_objects) (void)hipHostFree(ctx->pinned_objects);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -409,6 +465,12 @@ int rpt_upload_scene(rpt_ctx *ctx, const rpt_scene_desc *s) {
     ctx->octree_count = s->octree_count;
     ctx->octree_tri_count = s->octree_tri_count;
     if (int rc = build_derived_geometry(ctx, *s)) return rc;
+    ctx->host_node_bounds.resize(s->octree_count * 6);
+    for (size_t i = 0; i < s->octree_count; i++) {
+        float *b = &ctx->host_node_bounds[6 * i];
+        b[0] = s->octrees[i].min.x; b[1] = s->octrees[i].min.y; b[2] = s->octrees[i].min.z;
+        b[3] = s->octrees[i].max.x; b[4] = s->octrees[i].max.y; b[5] = s->octrees[i].max.z;
+    }
     ctx->scene_uploaded = true;
     const int rc = rpt_set_objects(ctx, s->objects, (int)s->object_count);
     if (rc) ctx->scene_uploaded = false;
@@ -437,11 +499,12 @@ int rpt_set_objects(rpt_ctx *ctx, const void *objects, int count) {
         // the staging copy must not be overwritten while a previous frame's transfer is in flight
         RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         std::memcpy(ctx->pinned_objects, objects, bytes);
-        build_dobjs((const rpt_object *)objects, count, (rptd::DObj *)((char *)ctx->pinned_objects + bytes));
+        build_dobjs(ctx, (const rpt_object *)objects, count, (rptd::DObj *)((char *)ctx->pinned_objects + bytes));
         RPT_HIP(ctx, hipMemcpyAsync(ctx->objects.ptr, ctx->pinned_objects, bytes, hipMemcpyHostToDevice, ctx->stream));
         RPT_HIP(ctx, hipMemcpyAsync(ctx->dobjs.ptr, (char *)ctx->pinned_objects + bytes, dbytes, hipMemcpyHostToDevice, ctx->stream));
     }
     ctx->object_count = count;
+    ctx->host_objects.assign((const uint8_t *)objects, (const uint8_t *)objects + bytes);
     return RPT_OK;
 }
 
@@ -452,8 +515,13 @@ int rpt_set_params(rpt_ctx *ctx, const float white_point[3], float ambient, int 
     ctx->ambient = ambient;
     ctx->width = width;
     ctx->height = height;
+    const bool interval_changed = ctx->interval != interval;
     ctx->interval = interval;
     ctx->params_set = true;
+    if (interval_changed && ctx->scene_uploaded && ctx->object_count > 0) {
+        const std::vector<uint8_t> copy = ctx->host_objects;      // the culling record of DObj uses `interval`
+        return rpt_set_objects(ctx, copy.data(), ctx->object_count);
+    }
     return RPT_OK;
 }
 
@@ -487,7 +555,7 @@ int rpt_set_debug_rgb(rpt_ctx *ctx, void *p) {
 }
 
 int rpt_set_variant(rpt_ctx *ctx, int variant) {
-    if (!ctx || variant < 0 || variant > 7) return RPT_ERR_ARG;
+    if (!ctx || variant < 0 || variant > 12) return RPT_ERR_ARG;
     ctx->variant = variant;
     return RPT_OK;
 }
@@ -636,6 +704,18 @@ int rpt_read_counters(rpt_ctx *ctx, unsigned long long out[8]) {
     RPT_HIP(ctx, hipSetDevice(ctx->device));
     RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     RPT_HIP(ctx, hipMemcpy(out, ctx->counters.ptr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return RPT_OK;
+}
+
+int rpt_read_wave_times(rpt_ctx *ctx, unsigned long long *out, size_t max_words, size_t *words) {
+    if (!ctx || !out || !words) return RPT_ERR_ARG;
+    if (!ctx->wave_times.ptr) return fail(ctx, RPT_ERR_STATE, "rpt_read_wave_times: render with the diagnostic variant (7) first");
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    size_t n = ctx->wave_times.bytes / sizeof(unsigned long long);
+    if (n > max_words) n = max_words;
+    RPT_HIP(ctx, hipMemcpy(out, ctx->wave_times.ptr, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    *words = n;
     return RPT_OK;
 }
 

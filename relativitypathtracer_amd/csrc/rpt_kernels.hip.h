@@ -43,8 +43,17 @@ struct alignas(16) DTri { float ax, ay, az, e1x; float e1y, e1z, e2x, e2y; float
 static_assert(sizeof(DTri) == 48, "DTri is three 16-B loads");
 // Per object, per frame: the primary-ray origin in object space (every primary ray of a frame
 // starts at the camera event, opencl_kernel.cl:386-389) and what follows from it alone.
-struct alignas(16) DObj { float ox, oy, oz; float sphere_c; float winding; int pad0, pad1, pad2; };
-static_assert(sizeof(DObj) == 32, "DObj");
+struct alignas(16) DObj {
+    float ox, oy, oz; float sphere_c;        // exact (kernel operation order): used by the intersectors
+    float winding;
+    // conservative culling data (approximate arithmetic is fine here, see rpt_tile_bin_kernel):
+    float cbx, cby, cbz;                     // bounding-sphere centre in object space
+    float rb;                                // bounding-sphere radius, inflated; < 0 = never cull this object
+    float B[9];                              // object-space direction = B * nd + b for a camera direction nd
+    float b[3];
+    float pad[3];
+};
+static_assert(sizeof(DObj) == 96, "DObj");
 
 struct KernelArgs {
     const DNode *dnodes;
@@ -62,6 +71,7 @@ struct KernelArgs {
     rpt_pixel *out16;        // 16 B/pixel framebuffer (full frame addressing) or null
     uint32_t *plane;         // compact 4 B/pixel colour plane (local tile addressing) or null
     float *debug_rgb;        // 3 floats/pixel, full frame addressing, or null
+    unsigned long long *wave_times; // diagnostic builds only (variant 7): per wave {start, end} of s_memrealtime (100 MHz)
     unsigned long long *counters;   // diagnostic builds only (variant 7): [0..2] lane-level leaf/tri/descent
                                     // iterations, [3..5] the same counted once per executing wave
     float hable_wp[3];       // hable(white_point), host-computed
@@ -73,6 +83,12 @@ struct KernelArgs {
     int width, height;
     int interval;
     int first_tile, tile_step;
+    // tile binning (variant 12): 8x8-pixel tiles of this context's rows, classified once per frame
+    int tiles_x, n_tiles;                    // tiles per row, tiles in this context's rows
+    unsigned long long *tile_masks;          // [n_tiles] bit i = primary rays of the tile may hit object i (i < 64)
+    unsigned int *bin_counts;                // [3] tiles with a mesh candidate / analytic candidates only / none
+    unsigned int *bin_lists;                 // [3][n_tiles] tile ids per class
+    unsigned long long mesh_object_bits;     // which of the first 64 objects are meshes
 };
 
 struct Hit {                 // opencl_kernel.cl:38-44
@@ -275,7 +291,7 @@ RPT_DEV void count_iter(const KernelArgs &a, int which) {
 template <int V>
 RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &newRay, f3 world_origin,
                          float world_dirlen, Hit &hit) {
-    NodeRef<(V == 0 ? 0 : 1)> node;
+    NodeRef<(V == 0 ? 0 : 1)> node;   // V >= 1: derived layouts
     int currOctreeIndex = obj.meshIndex;
     node.load(a, currOctreeIndex);
     f2 d;
@@ -343,6 +359,10 @@ RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &
         uv = nmin + uv * extents;
         currOctreeIndex = node.neighbor(a, farSide);
         if (length(uv - newRay.origin) > hit.dist) break;
+    }
+    if (V == 2) {   // diagnostic: longest single walk (leaf steps) and a coarse histogram of walk lengths
+        atomicMax(&a.counters[6], (unsigned long long)steps);
+        if (steps > 32) atomicAdd(&a.counters[7], 1ull);
     }
     if (!didHit) return false;
 
@@ -528,7 +548,7 @@ RPT_DEV bool sample_light_occluded(const KernelArgs &a, f4 origin4, f4 dir4, flo
 // Returns false (and leaves `color` untouched) when the ray hits nothing: the caller then uses the
 // per-frame background constants instead of tonemapping (0.15,0.15,0.25) again for every pixel.
 template <int V>
-RPT_DEV bool trace(const KernelArgs &a, f3 camdir, f3 &color_out) {
+RPT_DEV bool trace(const KernelArgs &a, f3 camdir, unsigned long long object_mask, f3 &color_out) {
     const float inf = 1e20f;
     Hit hit;
     hit.dist = inf;
@@ -537,6 +557,9 @@ RPT_DEV bool trace(const KernelArgs &a, f3 camdir, f3 &color_out) {
     const f4 rayDir = mk4((float)a.interval, nd.x, nd.y, nd.z);
 
     for (int i = 0; i < a.object_count; i++) {
+        // wave-uniform skip of objects whose bounding volume no ray of this tile can reach (a miss for every
+        // lane in the reference too, so skipping it changes nothing)
+        if (i < 64 && !((object_mask >> i) & 1ull)) continue;
         Hit newHit;
         newHit.dist = inf;
         bool got;
@@ -550,6 +573,10 @@ RPT_DEV bool trace(const KernelArgs &a, f3 camdir, f3 &color_out) {
         }
     }
     if (hit.object < 0) return false;
+    if (V == 3) {   // diagnostic: stop after the closest hit (timing of the primary walk alone; not a product path)
+        color_out = mk3(hit.dist, hit.normal.x + hit.uv.x, hit.normal.y + hit.normal.z + hit.uv.y);
+        return true;
+    }
 
     const rpt_object &ho = a.objects[hit.object];
     f3 hcolor = ho.textureIndex != -1 ? sample_texture(a, ho, hit.uv) : ld3(ho.color);
@@ -627,6 +654,8 @@ template <int V>
 RPT_DEV void render_pixel_body(const KernelArgs &a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    unsigned long long t_start = 0;
+    if (V == 4) t_start = wall_clock64();
     const int x_coord = blockIdx.x * 32 + wave * 8 + (lane & 7);
     const int local_row = blockIdx.y * RPT_TILE_ROWS + (lane >> 3);
     const int y_coord = (a.first_tile + (int)blockIdx.y * a.tile_step) * RPT_TILE_ROWS + (lane >> 3);
@@ -636,8 +665,157 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
     f3 color;
     f3 mapped = mk3(a.bg_mapped[0], a.bg_mapped[1], a.bg_mapped[2]);
     uint32_t packed = a.bg_packed;
-    if (trace<V>(a, camdir, color)) packed = tonemap_pack(a, color, mapped);
+    if (trace<V>(a, camdir, ~0ull, color)) packed = tonemap_pack(a, color, mapped);
 
+    const size_t id = (size_t)y_coord * a.width + x_coord;
+    if (a.out16) {
+        uint4 px;
+        px.x = __float_as_uint((float)x_coord);
+        px.y = __float_as_uint((float)y_coord);
+        px.z = packed;
+        px.w = 0u;
+        reinterpret_cast<uint4 *>(a.out16)[id] = px;
+    }
+    if (a.plane) a.plane[(size_t)local_row * a.width + x_coord] = packed;
+    if (a.debug_rgb) {
+        a.debug_rgb[3 * id + 0] = mapped.x;
+        a.debug_rgb[3 * id + 1] = mapped.y;
+        a.debug_rgb[3 * id + 2] = mapped.z;
+    }
+    if (V == 4 && a.wave_times) {
+        const unsigned long long t_end = wall_clock64();
+        const unsigned long long m = __ballot(1);
+        if (lane == __ffsll((long long)m) - 1) {
+            const size_t w = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+            a.wave_times[2 * w] = t_start;
+            a.wave_times[2 * w + 1] = t_end;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rpt_render_kernel_v0(const KernelArgs a) { render_pixel_body<0>(a); }
+__global__ __launch_bounds__(256) void rpt_render_kernel_v1(const KernelArgs a) { render_pixel_body<1>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_w4(const KernelArgs a) { render_pixel_body<1>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_v1_w5(const KernelArgs a) { render_pixel_body<1>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_v1_w6(const KernelArgs a) { render_pixel_body<1>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_v1_w8(const KernelArgs a) { render_pixel_body<1>(a); }
+__global__ __launch_bounds__(256) void rpt_render_kernel_v1_diag(const KernelArgs a) { render_pixel_body<2>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_timeline(const KernelArgs a) { render_pixel_body<4>(a); }
+__global__ __launch_bounds__(256) void rpt_render_kernel_primary_only(const KernelArgs a) { render_pixel_body<3>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_primary_only_w6(const KernelArgs a) { render_pixel_body<3>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_primary_only_w8(const KernelArgs a) { render_pixel_body<3>(a); }
+
+// ---------------------------------------------------------------------------------------------
+// Tile binning prepass (one thread per 8x8 tile).  For every object it asks whether ANY primary ray
+// of the tile can reach the object's bounding sphere: the tile's rays (object space) lie in a cone
+// around the centre ray whose half-angle is taken from the four corner rays (of the tile grown by
+// half a pixel) with a 1.5x safety factor; the sphere subtends asin(r/d) around the direction to its
+// centre; the object is dropped for the tile only if the two cones are clearly disjoint.  Radii are
+// inflated on the host and every doubtful case (origin inside or near the sphere, degenerate or
+// non-finite directions, wide tiles) keeps the object.  The arithmetic here is approximate on
+// purpose: it only decides which exact tests are skipped, and a skipped test is one the reference
+// would have failed for every pixel of the tile.
+RPT_DEV f3 cull_dir(const DObj &o, f3 nd) {
+    return mk3(o.B[0] * nd.x + o.B[1] * nd.y + o.B[2] * nd.z + o.b[0],
+               o.B[3] * nd.x + o.B[4] * nd.y + o.B[5] * nd.z + o.b[1],
+               o.B[6] * nd.x + o.B[7] * nd.y + o.B[8] * nd.z + o.b[2]);
+}
+
+__global__ __launch_bounds__(256) void rpt_tile_bin_kernel(const KernelArgs a) {
+    const int tile = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = tile < a.n_tiles;
+    unsigned long long mask = 0;
+    if (valid) {
+        const int tx = tile % a.tiles_x, trow = tile / a.tiles_x;
+        const float x0 = (float)(tx * 8), y0 = (float)((a.first_tile + trow * a.tile_step) * RPT_TILE_ROWS);
+        const float xs[5] = {x0 + 3.5f, x0 - 0.5f, x0 + 7.5f, x0 - 0.5f, x0 + 7.5f};
+        const float ys[5] = {y0 + 3.5f, y0 - 0.5f, y0 - 0.5f, y0 + 7.5f, y0 + 7.5f};
+        f3 nd[5];
+        for (int k = 0; k < 5; k++) {
+            const f3 p = mk3((xs[k] / (float)a.width - 0.5f) * a.aspect, ys[k] / (float)a.height - 0.5f, 0.5f);
+            nd[k] = p * (1.0f / __builtin_sqrtf(dot(p, p)));
+        }
+        const int n = a.object_count < 64 ? a.object_count : 64;
+        for (int i = 0; i < n; i++) {
+            const DObj &o = a.dobjs[i];
+            bool keep = true;
+            if (o.rb >= 0.0f) {
+                f3 u[5];
+                float lmin = 3.0e38f, lmax = 0.0f;
+                for (int k = 0; k < 5; k++) {
+                    const f3 d = cull_dir(o, nd[k]);
+                    const float l = __builtin_sqrtf(dot(d, d));
+                    lmin = l < lmin ? l : lmin;
+                    lmax = l > lmax ? l : lmax;
+                    u[k] = d * (1.0f / l);
+                }
+                // angles from atan2(|u x v|, u . v): accurate for the tiny angles that strongly anisotropic
+                // object scales produce (acos of a cosine near 1 loses them in fp32)
+                float thTile = 0.0f;
+                for (int k = 1; k < 5; k++) {
+                    const f3 cr = cross(u[0], u[k]);
+                    const float t = atan2f(__builtin_sqrtf(dot(cr, cr)), dot(u[0], u[k]));
+                    thTile = t > thTile ? t : thTile;
+                }
+                const f3 to = mk3(o.cbx - o.ox, o.cby - o.oy, o.cbz - o.oz);
+                const float dist = __builtin_sqrtf(dot(to, to));
+                const bool sane = (lmin > 0.05f * lmax) && (lmax < 1.0e30f) && (dist > 1.05f * o.rb) && (dist < 1.0e30f) && (thTile < 0.25f);
+                if (sane) {
+                    const f3 ca = cross(u[0], to);
+                    const float ang = atan2f(__builtin_sqrtf(dot(ca, ca)), dot(u[0], to));
+                    const float thObj = asinf(fminf(o.rb / dist, 1.0f));
+                    keep = !(ang > thObj + 1.5f * thTile + 1.0e-4f);     // NaN anywhere -> keep
+                }
+            }
+            if (keep) mask |= 1ull << i;
+        }
+        if (a.object_count > 64) mask |= 0ull;   // objects >= 64 are never culled (trace() tests them always)
+        a.tile_masks[tile] = mask;
+    }
+    // class 0: a mesh may be hit (octree walk: the long waves, scheduled first); 1: analytic objects only;
+    // 2: nothing (background fill).  With more than 64 objects every tile is at least class 1.
+    int cls = 2;
+    if (mask & a.mesh_object_bits) cls = 0;
+    else if (mask || a.object_count > 64) cls = 1;
+    for (int c = 0; c < 3; c++) {           // wave-aggregated append
+        const unsigned long long m = __ballot(valid && cls == c);
+        if (m) {
+            const int lane = threadIdx.x & 63;
+            unsigned int base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&a.bin_counts[c], (unsigned int)__popcll(m));
+            base = __shfl(base, __ffsll((long long)m) - 1);
+            if (valid && cls == c) a.bin_lists[(size_t)c * a.n_tiles + base + __popcll(m & ((1ull << lane) - 1))] = (unsigned int)tile;
+        }
+    }
+}
+
+// Binned main kernel: one wave per tile, tiles taken from the class lists in the order
+// mesh -> analytic -> empty, so the long octree-walk waves start first and the cheap ones fill the tail.
+template <int V>
+RPT_DEV void render_tile_body(const KernelArgs &a) {
+    const int lane = threadIdx.x & 63;
+    const int g = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (g >= a.n_tiles) return;
+    const unsigned int c0 = a.bin_counts[0], c1 = a.bin_counts[1];
+    unsigned int slot;
+    if ((unsigned)g < c0) slot = (unsigned)g;
+    else if ((unsigned)g < c0 + c1) slot = (unsigned)a.n_tiles + ((unsigned)g - c0);
+    else slot = 2u * (unsigned)a.n_tiles + ((unsigned)g - c0 - c1);
+    const int tile = __builtin_amdgcn_readfirstlane((int)a.bin_lists[slot]);
+    const unsigned long long mask = a.tile_masks[tile];
+    const int tx = tile % a.tiles_x, trow = tile / a.tiles_x;
+    const int x_coord = tx * 8 + (lane & 7);
+    const int local_row = trow * RPT_TILE_ROWS + (lane >> 3);
+    const int y_coord = (a.first_tile + trow * a.tile_step) * RPT_TILE_ROWS + (lane >> 3);
+    if (x_coord >= a.width || y_coord >= a.height) return;
+
+    f3 mapped = mk3(a.bg_mapped[0], a.bg_mapped[1], a.bg_mapped[2]);
+    uint32_t packed = a.bg_packed;
+    if (mask != 0 || a.object_count > 64) {
+        const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);
+        f3 color;
+        if (trace<V>(a, camdir, mask, color)) packed = tonemap_pack(a, color, mapped);
+    }
     const size_t id = (size_t)y_coord * a.width + x_coord;
     if (a.out16) {
         uint4 px;
@@ -655,13 +833,7 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
     }
 }
 
-__global__ __launch_bounds__(256) void rpt_render_kernel_v0(const KernelArgs a) { render_pixel_body<0>(a); }
-__global__ __launch_bounds__(256) void rpt_render_kernel_v1(const KernelArgs a) { render_pixel_body<1>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_w4(const KernelArgs a) { render_pixel_body<1>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_v1_w5(const KernelArgs a) { render_pixel_body<1>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_v1_w6(const KernelArgs a) { render_pixel_body<1>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_v1_w8(const KernelArgs a) { render_pixel_body<1>(a); }
-__global__ __launch_bounds__(256) void rpt_render_kernel_v1_diag(const KernelArgs a) { render_pixel_body<2>(a); }
+__global__ __launch_bounds__(256) void rpt_render_binned_v1(const KernelArgs a) { render_tile_body<1>(a); }
 
 // Root-side reassembly after the gather: plane of rank r, local tile k -> global tile r + k*n_ranks.
 __global__ __launch_bounds__(256) void rpt_scatter_plane_kernel(const uint32_t *planes, rpt_pixel *out16, int width,

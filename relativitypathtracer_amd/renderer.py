@@ -151,6 +151,13 @@ class Renderer:
         self._check(self._lib.rpt_read_counters(self._h, out), "rpt_read_counters")
         return list(out)
 
+    def read_wave_times(self) -> np.ndarray:
+        n = ((self.width + 31) // 32) * self.local_tiles() * 4 * 2
+        out = np.zeros(n, dtype=np.uint64)
+        got = C.c_size_t()
+        self._check(self._lib.rpt_read_wave_times(self._h, out.ctypes.data, n, C.byref(got)), "rpt_read_wave_times")
+        return out[:got.value].reshape(-1, 2)
+
     def probe(self, which: int, inputs: np.ndarray, out_width: int) -> np.ndarray:
         inputs = np.ascontiguousarray(inputs, dtype=np.float32)
         n = inputs.shape[0]
