@@ -34,6 +34,10 @@ struct rpt_ctx {
 
     DeviceBuffer objects, vertices, normals, uvs, triangles, octrees, octreeTris, textures;
     DeviceBuffer counters, wave_times;
+    unsigned int *host_counts = nullptr;              // pinned read-back of the tile-class counters (grid-size estimate)
+    long long counts_config = -1;                     // configuration the read-back belongs to
+    unsigned int scene_epoch = 0;                     // bumped by rpt_upload_scene / rpt_set_params
+    unsigned int frame_parity = 0;
     DeviceBuffer tile_masks, bin_counts, bin_lists;   // tile binning (variant 12)
     std::vector<uint8_t> host_objects;                // last Object[] (DObj depends on `interval`: rebuilt when it changes)
     std::vector<float> host_node_bounds;              // min.xyz,max.xyz per octree node (culling spheres of mesh roots)
@@ -348,8 +352,16 @@ int launch(rpt_ctx *ctx) {
     const int tiles = local_tile_count(ctx);
     if (tiles == 0) return RPT_OK;
     const dim3 grid((ctx->width + 31) / 32, tiles);
-    // variant 0 = default: the derived-layout kernel when the octree allows it, else the general one
-    int v = ctx->variant == 0 ? 3 : ctx->variant;
+    // variant 0 = default: the derived-layout kernel when the octree allows it, else the general one; with
+    // several objects the tile-binned form (per-tile object masks) wins by a large factor, with two or three
+    // the plain per-pixel loop is as fast (measured: DESIGN.md §6)
+    int v = ctx->variant;
+    if (v == 0) {
+        bool has_mesh = false;
+        for (int i = 0; i < ctx->object_count; i++)
+            if (((const rpt_object *)ctx->host_objects.data())[i].type == RPT_MESH) has_mesh = true;
+        v = (ctx->object_count >= 8 || (ctx->object_count >= 4 && !has_mesh)) ? 13 : 3;
+    }
     if (!ctx->compact_ok) v = 1;
     switch (v) {
     case 1: hipLaunchKernelGGL(rptd::rpt_render_kernel_v0, grid, dim3(256), 0, ctx->stream, a); break;
@@ -365,30 +377,57 @@ int launch(rpt_ctx *ctx) {
         hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_diag, grid, dim3(256), 0, ctx->stream, a);
         break;
     case 11:
-        if (int rc = reserve(ctx, ctx->wave_times, (size_t)grid.x * grid.y * 4 * 2 * sizeof(unsigned long long))) return rc;
+        if (int rc = reserve(ctx, ctx->wave_times, (size_t)grid.x * grid.y * 4 * 10 * sizeof(unsigned long long))) return rc;
         RPT_HIP(ctx, hipMemsetAsync(ctx->wave_times.ptr, 0, ctx->wave_times.bytes, ctx->stream));
         a.wave_times = (unsigned long long *)ctx->wave_times.ptr;
         hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_timeline, grid, dim3(256), 0, ctx->stream, a);
         break;
-    case 12: {
+    case 12:
+    case 13: {
         const int tiles_x = (ctx->width + 7) / 8;
         const int n_tiles = tiles_x * tiles;
         if (int rc = reserve(ctx, ctx->tile_masks, (size_t)n_tiles * 8)) return rc;
-        if (int rc = reserve(ctx, ctx->bin_counts, 16)) return rc;
+        if (!ctx->bin_counts.ptr) {
+            if (int rc = reserve(ctx, ctx->bin_counts, 32)) return rc;            // two alternating sets of 4 counters
+            RPT_HIP(ctx, hipMemsetAsync(ctx->bin_counts.ptr, 0, 32, ctx->stream));
+            RPT_HIP(ctx, hipHostMalloc((void **)&ctx->host_counts, 16, hipHostMallocDefault));
+            std::memset(ctx->host_counts, 0xff, 16);                                // "unknown": first frames use the full grid
+        }
         if (int rc = reserve(ctx, ctx->bin_lists, (size_t)n_tiles * 3 * 4)) return rc;
         a.tiles_x = tiles_x;
         a.n_tiles = n_tiles;
         a.tile_masks = (unsigned long long *)ctx->tile_masks.ptr;
-        a.bin_counts = (unsigned int *)ctx->bin_counts.ptr;
+        a.bin_counts = (unsigned int *)ctx->bin_counts.ptr + 4 * (ctx->frame_parity & 1);
+        a.bin_counts_next = (unsigned int *)ctx->bin_counts.ptr + 4 * ((ctx->frame_parity + 1) & 1);
+        ctx->frame_parity++;
         a.bin_lists = (unsigned int *)ctx->bin_lists.ptr;
         a.mesh_object_bits = 0;
         for (int i = 0; i < ctx->object_count && i < 64; i++)
             if (((const rpt_object *)ctx->host_objects.data())[i].type == RPT_MESH) a.mesh_object_bits |= 1ull << i;
-        RPT_HIP(ctx, hipMemsetAsync(ctx->bin_counts.ptr, 0, 16, ctx->stream));
+        // list length estimate: what an earlier frame of this configuration counted (read back without a
+        // sync, so it may be a frame or two old) plus a margin; the kernel strides, so any value is correct
+        unsigned int est = (unsigned int)n_tiles;
+        const unsigned int seen = ctx->host_counts[0] + ctx->host_counts[1];
+        const long long config = ((long long)ctx->scene_epoch << 40) | ((long long)n_tiles << 12) | (long long)(ctx->first_tile & 0xfff);
+        if (ctx->host_counts[0] != 0xffffffffu && ctx->counts_config == config && seen <= (unsigned int)n_tiles)
+            est = seen + seen / 2 + 256;     // generous: an overestimate costs a few idle blocks, an underestimate serialises
+        else
+            std::memset(ctx->host_counts, 0xff, 16);
+        if (est > (unsigned int)n_tiles) est = (unsigned int)n_tiles;
+        ctx->counts_config = config;
+        a.main_blocks = (int)((est + 3) / 4);
+        if (a.main_blocks < 1) a.main_blocks = 1;
+        const int strips = ((tiles_x + 7) / 8) * tiles;
         hipLaunchKernelGGL(rptd::rpt_tile_bin_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, ctx->stream, a);
-        hipLaunchKernelGGL(rptd::rpt_render_binned_v1, dim3((n_tiles + 3) / 4), dim3(256), 0, ctx->stream, a);
+        RPT_HIP(ctx, hipMemcpyAsync(ctx->host_counts, a.bin_counts, 16, hipMemcpyDeviceToHost, ctx->stream));
+        const dim3 bgrid(a.main_blocks + (strips + 3) / 4);
+        if (v == 12) hipLaunchKernelGGL(rptd::rpt_render_binned_v1, bgrid, dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(rptd::rpt_render_binned_v1_w4, bgrid, dim3(256), 0, ctx->stream, a);
         break;
     }
+    case 15: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_pipe, grid, dim3(256), 0, ctx->stream, a); break;
+    case 16: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_pipe_w4, grid, dim3(256), 0, ctx->stream, a); break;
+    case 14: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_prio, grid, dim3(256), 0, ctx->stream, a); break;
     case 8: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only, grid, dim3(256), 0, ctx->stream, a); break;
     case 9: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only_w6, grid, dim3(256), 0, ctx->stream, a); break;
     case 10: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only_w8, grid, dim3(256), 0, ctx->stream, a); break;
@@ -414,6 +453,7 @@ int rpt_create(rpt_ctx **out, int device_ordinal) {
     if (!ctx) return RPT_ERR_NOMEM;
     ctx->device = device_ordinal;
     if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+
         hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) {
         rpt_destroy(ctx);
         return RPT_ERR_DEVICE;
@@ -427,6 +467,7 @@ void rpt_destroy(rpt_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    if (ctx->host_counts) (void)hipHostFree(ctx->host_counts);
     for (DeviceBuffer *b : {&ctx->objects, &ctx->vertices, &ctx->normals, &ctx->uvs, &ctx->triangles, &ctx->octrees,
                             &ctx->octreeTris, &ctx->textures, &ctx->dnodes, &ctx->dtris, &ctx->dobjs, &ctx->counters, &ctx->wave_times, &ctx->tile_masks, &ctx->bin_counts, &ctx->bin_lists, &ctx->owned_out, &ctx->owned_plane, &ctx->owned_rgb})
         release(*b);
@@ -464,6 +505,7 @@ int rpt_upload_scene(rpt_ctx *ctx, const rpt_scene_desc *s) {
     ctx->triangle_words = s->triangle_words;
     ctx->octree_count = s->octree_count;
     ctx->octree_tri_count = s->octree_tri_count;
+    ctx->scene_epoch++;
     if (int rc = build_derived_geometry(ctx, *s)) return rc;
     ctx->host_node_bounds.resize(s->octree_count * 6);
     for (size_t i = 0; i < s->octree_count; i++) {
@@ -516,6 +558,7 @@ int rpt_set_params(rpt_ctx *ctx, const float white_point[3], float ambient, int 
     ctx->width = width;
     ctx->height = height;
     const bool interval_changed = ctx->interval != interval;
+    if (interval_changed || ctx->width != width || ctx->height != height) ctx->scene_epoch++;
     ctx->interval = interval;
     ctx->params_set = true;
     if (interval_changed && ctx->scene_uploaded && ctx->object_count > 0) {
@@ -555,7 +598,7 @@ int rpt_set_debug_rgb(rpt_ctx *ctx, void *p) {
 }
 
 int rpt_set_variant(rpt_ctx *ctx, int variant) {
-    if (!ctx || variant < 0 || variant > 12) return RPT_ERR_ARG;
+    if (!ctx || variant < 0 || variant > 16) return RPT_ERR_ARG;
     ctx->variant = variant;
     return RPT_OK;
 }

@@ -86,7 +86,9 @@ struct KernelArgs {
     // tile binning (variant 12): 8x8-pixel tiles of this context's rows, classified once per frame
     int tiles_x, n_tiles;                    // tiles per row, tiles in this context's rows
     unsigned long long *tile_masks;          // [n_tiles] bit i = primary rays of the tile may hit object i (i < 64)
-    unsigned int *bin_counts;                // [3] tiles with a mesh candidate / analytic candidates only / none
+    unsigned int *bin_counts;                // [4] tiles with a mesh candidate / analytic candidates only / none
+    unsigned int *bin_counts_next;           // the other buffer of the pair, zeroed by the main kernel for the next frame
+    int main_blocks;                         // blocks of the binned kernel that walk the tile lists
     unsigned int *bin_lists;                 // [3][n_tiles] tile ids per class
     unsigned long long mesh_object_bits;     // which of the first 64 objects are meshes
 };
@@ -177,6 +179,23 @@ RPT_DEV int getOppositeBoxSide(const ExitPlan &p, f3 &uv) {
     }
     uv = uv + p.scaledDir * t;
     return side;
+}
+
+// The same step for the common case 0 <= uv < 1.5 on every axis (+0 included, -0/NaN/negative excluded by
+// the unsigned compare on the bit patterns): there round(c) is (c >= 0.5), min(c, 1-eps) keeps that bit, and
+// 2*fmod(m, 0.5) is 2*(m - 0.5*bit) — every operation exact, so the results are those of the general form.
+RPT_DEV int octree_child_step(f3 &uv);
+RPT_DEV int octree_child_step_fast(f3 &uv) {
+    const unsigned int lim = 0x3FC00000u;   // 1.5f
+    const bool in_range = (__float_as_uint(uv.x) < lim) & (__float_as_uint(uv.y) < lim) & (__float_as_uint(uv.z) < lim);
+    if (!in_range) return octree_child_step(uv);
+    const float top = 1.0f - RPT_EPSILON;
+    const bool bx = uv.x >= 0.5f, by = uv.y >= 0.5f, bz = uv.z >= 0.5f;
+    const float mx = top < uv.x ? top : uv.x, my = top < uv.y ? top : uv.y, mz = top < uv.z ? top : uv.z;
+    uv.x = 2.0f * (mx - (bx ? 0.5f : 0.0f));
+    uv.y = 2.0f * (my - (by ? 0.5f : 0.0f));
+    uv.z = 2.0f * (mz - (bz ? 0.5f : 0.0f));
+    return (bz ? 1 : 0) + (by ? 2 : 0) + (bx ? 4 : 0);
 }
 
 // child selection and re-normalisation of opencl_kernel.cl:237-238 / 257-258
@@ -275,6 +294,19 @@ RPT_DEV bool intersect_triangle_edges(f3 A, f3 v0v1, f3 v0v2, const Ray &ray, fl
 
 // opencl_kernel.cl:200-308 from the point where the ray is in object space.  newRay = object-space
 // ray (direction normalised); world_origin/world_dirlen are ray->origin.yzw and |ray->dir.yzw|.
+// Diagnostic cycle accounting (V == 4 only): per wave, shader-clock cycles and wave-level iteration counts of
+// the three loops of the walk, accumulated in LDS by the first active lane.
+__shared__ unsigned long long rpt_diag_lds[4][8];
+template <int V>
+RPT_DEV void diag_add(int slot, unsigned long long v) {
+    if (V == 4) {
+        const unsigned long long m = __ballot(1);
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) rpt_diag_lds[threadIdx.x >> 6][slot] += v;
+    }
+}
+template <int V>
+RPT_DEV unsigned long long diag_clock() { return V == 4 ? (unsigned long long)clock64() : 0ull; }
+
 // Diagnostic counting (V == 2 only): how many loop iterations lanes need vs. how many the wave executes.
 template <int V>
 RPT_DEV void count_iter(const KernelArgs &a, int which) {
@@ -298,12 +330,163 @@ RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &
     int closeSide, farSide;
     f3 nmin = node.bmin(a), nmax = node.bmax(a);
     if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
+    // waves that walk the octree are the frame's critical path: let them issue ahead of the cheap waves
+    if (V == 5) __builtin_amdgcn_s_setprio(3);
     f3 uv = newRay.origin + newRay.dir * d.x;
 
     if (d.x < 0) {   // ray starts inside the root: descend to the leaf holding the origin
         uv = (newRay.origin - nmin) / (nmax - nmin);
         while (!node.is_leaf(a)) {
             const int childIndex = octree_child_step(uv);
+            currOctreeIndex = node.child(a, childIndex);
+            node.load(a, currOctreeIndex);
+        }
+        nmin = node.bmin(a);
+        nmax = node.bmax(a);
+        if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) {
+            if (V == 5) __builtin_amdgcn_s_setprio(0);
+            return false;
+        }
+        uv = newRay.origin + newRay.dir * d.x;
+    }
+
+    const ExitPlan plan = makeExitPlan(normalize(newRay.dir / (nmax - nmin)));
+    bool didHit = false;
+    int hitTri = 0;
+    int steps = 0;
+    while (currOctreeIndex != -1) {
+        if (++steps > RPT_MAX_LEAF_STEPS) break;
+        count_iter<V>(a, 0);
+        const unsigned long long t_leaf0 = diag_clock<V>();
+        node.load(a, currOctreeIndex);
+        nmin = node.bmin(a);
+        nmax = node.bmax(a);
+        uv = (uv - nmin) / (nmax - nmin);
+        bool descended = false;
+        const unsigned long long t_desc0 = diag_clock<V>();
+        while (!node.is_leaf(a)) {
+            const int childIndex = octree_child_step(uv);
+            currOctreeIndex = node.child(a, childIndex);
+            node.load(a, currOctreeIndex);
+            descended = true;
+            count_iter<V>(a, 2);
+            diag_add<V>(3, 1);
+        }
+        const unsigned long long t_tri0 = diag_clock<V>();
+        diag_add<V>(2, t_tri0 - t_desc0);
+        if (descended) {
+            nmin = node.bmin(a);
+            nmax = node.bmax(a);
+        }
+        const int trisIndex = node.tri_begin(a);
+        const int trisEnd = trisIndex + node.tri_count(a);
+        for (int i = trisIndex; i < trisEnd; i++) {
+            f3 A, v0v1, v0v2;
+            int tri;
+            node.tri(a, i, A, v0v1, v0v2, tri);
+            count_iter<V>(a, 1);
+            diag_add<V>(1, 1);
+            float dist;
+            f2 triUV;
+            if (intersect_triangle_edges(A, v0v1, v0v2, newRay, dist, triUV)) {
+                if (0 <= dist && dist < hit.dist) {
+                    hitTri = tri;
+                    hit.dist = dist;
+                    hit.uv = triUV;
+                    didHit = true;
+                }
+            }
+        }
+        const unsigned long long t_tri1 = diag_clock<V>();
+        diag_add<V>(0, t_tri1 - t_tri0);
+        const f3 extents = nmax - nmin;
+        farSide = getOppositeBoxSide(plan, uv);
+        uv = nmin + uv * extents;
+        currOctreeIndex = node.neighbor(a, farSide);
+        const bool stop = length(uv - newRay.origin) > hit.dist;
+        diag_add<V>(4, (diag_clock<V>() - t_tri1) + (t_desc0 - t_leaf0));
+        diag_add<V>(5, 1);
+        if (stop) break;
+    }
+    if (V == 5) __builtin_amdgcn_s_setprio(0);
+    if (V == 2) {   // diagnostic: longest single walk (leaf steps) and a coarse histogram of walk lengths
+        atomicMax(&a.counters[6], (unsigned long long)steps);
+        if (steps > 32) atomicAdd(&a.counters[7], 1ull);
+    }
+    if (!didHit) return false;
+
+    const float u = hit.uv.x, v = hit.uv.y;
+    const float w = 1.0f - u - v;
+    const f3 normA = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 0]]);
+    const f3 normB = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 1]]);
+    const f3 normC = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 2]]);
+    hit.normal = normalize(applyTranspose(obj.InvM, normA * w + normB * u + normC * v));
+    const rpt_float2 uvA = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 0]];
+    const rpt_float2 uvB = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 1]];
+    const rpt_float2 uvC = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 2]];
+    hit.uv.x = w * uvA.x + u * uvB.x + v * uvC.x;
+    hit.uv.y = w * uvA.y + u * uvB.y + v * uvC.y;
+    const f3 objPoint = newRay.origin + newRay.dir * hit.dist;
+    const f3 worldPoint = transformPoint(obj.M, objPoint);
+    hit.dist = length(worldPoint - world_origin) / world_dirlen;
+    return true;
+}
+
+// The same walk with its memory latency taken off the dependent chain (derived layouts only):
+//   * the exit face and the neighbour index of a leaf depend only on (uv, bounds), not on its triangles,
+//     so they are computed FIRST and the neighbour's 64-B record is requested before the triangle loop;
+//   * triangle records of a leaf are contiguous: record k+1 is requested before record k is tested.
+// Per leaf step the only loads left on the critical path are the descent levels.  Arithmetic and the
+// order of hit updates are those of octree_core (the break test still sees the leaf's final hit.dist).
+struct DTriRec { f3 A, v0v1, v0v2; int id; };
+
+RPT_DEV DTriRec load_dtri(const KernelArgs &a, int k) {
+    const v4f *p = reinterpret_cast<const v4f *>(a.dtris + k);
+    const v4f t0 = p[0], t1 = p[1], t2 = p[2];
+    DTriRec r;
+    r.A = mk3(t0.x, t0.y, t0.z);
+    r.v0v1 = mk3(t0.w, t1.x, t1.y);
+    r.v0v2 = mk3(t1.z, t1.w, t2.x);
+    r.id = __float_as_int(t2.y);
+    return r;
+}
+
+// Two triangles of a leaf at once, without branches: both Moller-Trumbore chains are independent and
+// interleave (ILP for a wave that is alone on its SIMD), and the six record loads are one round trip.
+// Accept/reject and the update order are those of the sequential loop (first `a`, then `b`).
+RPT_DEV void tri_update(const DTriRec &t, const Ray &ray, bool valid, Hit &hit, int &hitTri, bool &didHit) {
+    const f3 pvec = cross(ray.dir, t.v0v2);
+    const float det = dot(t.v0v1, pvec);
+    const float invDet = 1 / det;
+    const f3 tvec = ray.origin - t.A;
+    const float u = dot(tvec, pvec) * invDet;
+    const f3 qvec = cross(tvec, t.v0v1);
+    const float v = dot(ray.dir, qvec) * invDet;
+    const float dist = dot(t.v0v2, qvec) * invDet;
+    const bool reject = (det < RPT_EPSILON && -RPT_EPSILON < det) || (u < 0 || u > 1) || (v < 0 || u + v > 1);
+    const bool take = valid && !reject && (0 <= dist && dist < hit.dist);
+    hitTri = take ? t.id : hitTri;
+    hit.dist = take ? dist : hit.dist;
+    hit.uv.x = take ? u : hit.uv.x;
+    hit.uv.y = take ? v : hit.uv.y;
+    didHit = didHit || take;
+}
+
+RPT_DEV bool octree_core_pipelined(const KernelArgs &a, const rpt_object &obj, const Ray &newRay, f3 world_origin,
+                                   float world_dirlen, Hit &hit) {
+    NodeRef<1> node;
+    int currOctreeIndex = obj.meshIndex;
+    node.load(a, currOctreeIndex);
+    f2 d;
+    int closeSide, farSide;
+    f3 nmin = node.bmin(a), nmax = node.bmax(a);
+    if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
+    f3 uv = newRay.origin + newRay.dir * d.x;
+
+    if (d.x < 0) {
+        uv = (newRay.origin - nmin) / (nmax - nmin);
+        while (!node.is_leaf(a)) {
+            const int childIndex = octree_child_step_fast(uv);
             currOctreeIndex = node.child(a, childIndex);
             node.load(a, currOctreeIndex);
         }
@@ -317,52 +500,42 @@ RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &
     bool didHit = false;
     int hitTri = 0;
     int steps = 0;
-    while (currOctreeIndex != -1) {
+    // invariant at the top of the loop: `node` holds the record of currOctreeIndex (!= -1)
+    while (true) {
         if (++steps > RPT_MAX_LEAF_STEPS) break;
-        count_iter<V>(a, 0);
-        node.load(a, currOctreeIndex);
         nmin = node.bmin(a);
         nmax = node.bmax(a);
         uv = (uv - nmin) / (nmax - nmin);
         bool descended = false;
         while (!node.is_leaf(a)) {
-            const int childIndex = octree_child_step(uv);
+            const int childIndex = octree_child_step_fast(uv);
             currOctreeIndex = node.child(a, childIndex);
             node.load(a, currOctreeIndex);
             descended = true;
-            count_iter<V>(a, 2);
         }
         if (descended) {
             nmin = node.bmin(a);
             nmax = node.bmax(a);
         }
-        const int trisIndex = node.tri_begin(a);
-        const int trisEnd = trisIndex + node.tri_count(a);
-        for (int i = trisIndex; i < trisEnd; i++) {
-            f3 A, v0v1, v0v2;
-            int tri;
-            node.tri(a, i, A, v0v1, v0v2, tri);
-            count_iter<V>(a, 1);
-            float dist;
-            f2 triUV;
-            if (intersect_triangle_edges(A, v0v1, v0v2, newRay, dist, triUV)) {
-                if (0 <= dist && dist < hit.dist) {
-                    hitTri = tri;
-                    hit.dist = dist;
-                    hit.uv = triUV;
-                    didHit = true;
-                }
-            }
-        }
+        int k = node.tri_begin(a);
+        const int kend = k + node.tri_count(a);
         const f3 extents = nmax - nmin;
         farSide = getOppositeBoxSide(plan, uv);
         uv = nmin + uv * extents;
-        currOctreeIndex = node.neighbor(a, farSide);
+        const int nextIndex = node.neighbor(a, farSide);
+        NodeRef<1> nextNode;
+        nextNode.load(a, nextIndex < 0 ? currOctreeIndex : nextIndex);   // always a valid record: no branch around the loads
+        while (k < kend) {
+            const DTriRec ta = load_dtri(a, k);
+            const DTriRec tb = load_dtri(a, k + 1 < kend ? k + 1 : k);
+            tri_update(ta, newRay, true, hit, hitTri, didHit);
+            tri_update(tb, newRay, k + 1 < kend, hit, hitTri, didHit);
+            k += 2;
+        }
+        currOctreeIndex = nextIndex;
         if (length(uv - newRay.origin) > hit.dist) break;
-    }
-    if (V == 2) {   // diagnostic: longest single walk (leaf steps) and a coarse histogram of walk lengths
-        atomicMax(&a.counters[6], (unsigned long long)steps);
-        if (steps > 32) atomicAdd(&a.counters[7], 1ull);
+        if (currOctreeIndex == -1) break;
+        node = nextNode;
     }
     if (!didHit) return false;
 
@@ -455,6 +628,7 @@ RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, H
         Ray newRay;
         newRay.origin = origin;
         newRay.dir = dir;
+        if (V == 6) return octree_core_pipelined(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
         return octree_core<V>(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
     }
     default:
@@ -483,7 +657,9 @@ RPT_DEV bool intersect_object_primary(const KernelArgs &a, int i, f4 rayDir, Hit
         Ray newRay;
         newRay.origin = origin;
         newRay.dir = dir;
-        return octree_core<V>(a, obj, newRay, mk3(obj.stationaryCam.y, obj.stationaryCam.z, obj.stationaryCam.w), length(d3), hit);
+        const f3 cam3 = mk3(obj.stationaryCam.y, obj.stationaryCam.z, obj.stationaryCam.w);
+        if (V == 6) return octree_core_pipelined(a, obj, newRay, cam3, length(d3), hit);
+        return octree_core<V>(a, obj, newRay, cam3, length(d3), hit);
     }
     default:
         return false;
@@ -655,7 +831,11 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     unsigned long long t_start = 0;
-    if (V == 4) t_start = wall_clock64();
+    if (V == 4) {
+        t_start = wall_clock64();
+        if ((threadIdx.x & 63) < 8) rpt_diag_lds[threadIdx.x >> 6][threadIdx.x & 63] = 0;
+        rpt_diag_lds[threadIdx.x >> 6][6] = clock64();
+    }
     const int x_coord = blockIdx.x * 32 + wave * 8 + (lane & 7);
     const int local_row = blockIdx.y * RPT_TILE_ROWS + (lane >> 3);
     const int y_coord = (a.first_tile + (int)blockIdx.y * a.tile_step) * RPT_TILE_ROWS + (lane >> 3);
@@ -687,8 +867,10 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
         const unsigned long long m = __ballot(1);
         if (lane == __ffsll((long long)m) - 1) {
             const size_t w = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
-            a.wave_times[2 * w] = t_start;
-            a.wave_times[2 * w + 1] = t_end;
+            a.wave_times[10 * w] = t_start;
+            a.wave_times[10 * w + 1] = t_end;
+            rpt_diag_lds[wave][7] = clock64();
+            for (int q = 0; q < 8; q++) a.wave_times[10 * w + 2 + q] = rpt_diag_lds[wave][q];
         }
     }
 }
@@ -701,6 +883,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_v1_w8(const KernelArgs a) { render_pixel_body<1>(a); }
 __global__ __launch_bounds__(256) void rpt_render_kernel_v1_diag(const KernelArgs a) { render_pixel_body<2>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_timeline(const KernelArgs a) { render_pixel_body<4>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_prio(const KernelArgs a) { render_pixel_body<5>(a); }
+__global__ __launch_bounds__(256) void rpt_render_kernel_v1_pipe(const KernelArgs a) { render_pixel_body<6>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_pipe_w4(const KernelArgs a) { render_pixel_body<6>(a); }
 __global__ __launch_bounds__(256) void rpt_render_kernel_primary_only(const KernelArgs a) { render_pixel_body<3>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_primary_only_w6(const KernelArgs a) { render_pixel_body<3>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_primary_only_w8(const KernelArgs a) { render_pixel_body<3>(a); }
@@ -789,33 +974,25 @@ __global__ __launch_bounds__(256) void rpt_tile_bin_kernel(const KernelArgs a) {
     }
 }
 
-// Binned main kernel: one wave per tile, tiles taken from the class lists in the order
-// mesh -> analytic -> empty, so the long octree-walk waves start first and the cheap ones fill the tail.
+// Binned main kernel, one launch: blocks [0, main_blocks) render the NON-EMPTY tiles, one wave per tile,
+// taken from the class lists in the order mesh -> analytic, so the long octree-walk waves are dispatched
+// first and the cheap ones fill the tail; main_blocks is the host's estimate of the list length (last
+// frame's count plus a margin) and the waves stride over the lists, so any estimate is correct.  Blocks
+// [main_blocks, gridDim.x) write the background of the empty tiles: one wave owns a 64x8 strip = 8
+// consecutive tiles of a tile row, reads their masks and streams the empty ones out (no per-pixel math).
 template <int V>
-RPT_DEV void render_tile_body(const KernelArgs &a) {
-    const int lane = threadIdx.x & 63;
-    const int g = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (g >= a.n_tiles) return;
-    const unsigned int c0 = a.bin_counts[0], c1 = a.bin_counts[1];
-    unsigned int slot;
-    if ((unsigned)g < c0) slot = (unsigned)g;
-    else if ((unsigned)g < c0 + c1) slot = (unsigned)a.n_tiles + ((unsigned)g - c0);
-    else slot = 2u * (unsigned)a.n_tiles + ((unsigned)g - c0 - c1);
-    const int tile = __builtin_amdgcn_readfirstlane((int)a.bin_lists[slot]);
+RPT_DEV void render_one_tile(const KernelArgs &a, int tile, int lane) {
     const unsigned long long mask = a.tile_masks[tile];
     const int tx = tile % a.tiles_x, trow = tile / a.tiles_x;
     const int x_coord = tx * 8 + (lane & 7);
     const int local_row = trow * RPT_TILE_ROWS + (lane >> 3);
     const int y_coord = (a.first_tile + trow * a.tile_step) * RPT_TILE_ROWS + (lane >> 3);
     if (x_coord >= a.width || y_coord >= a.height) return;
-
     f3 mapped = mk3(a.bg_mapped[0], a.bg_mapped[1], a.bg_mapped[2]);
     uint32_t packed = a.bg_packed;
-    if (mask != 0 || a.object_count > 64) {
-        const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);
-        f3 color;
-        if (trace<V>(a, camdir, mask, color)) packed = tonemap_pack(a, color, mapped);
-    }
+    const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);
+    f3 color;
+    if (trace<V>(a, camdir, mask, color)) packed = tonemap_pack(a, color, mapped);
     const size_t id = (size_t)y_coord * a.width + x_coord;
     if (a.out16) {
         uint4 px;
@@ -833,7 +1010,58 @@ RPT_DEV void render_tile_body(const KernelArgs &a) {
     }
 }
 
-__global__ __launch_bounds__(256) void rpt_render_binned_v1(const KernelArgs a) { render_tile_body<1>(a); }
+RPT_DEV void fill_strip(const KernelArgs &a, int strip, int lane) {
+    const int strips_x = (a.tiles_x + 7) / 8;
+    const int n_rows = a.n_tiles / a.tiles_x;
+    if (strip >= strips_x * n_rows) return;
+    const int trow = strip / strips_x, tx0 = (strip % strips_x) * 8;
+    const int y_coord = (a.first_tile + trow * a.tile_step) * RPT_TILE_ROWS + (lane >> 3);
+    const int local_row = trow * RPT_TILE_ROWS + (lane >> 3);
+    const bool many = a.object_count > 64;      // objects beyond the mask are always tested: no tile is "empty"
+    for (int t = 0; t < 8; t++) {
+        const int tx = tx0 + t;
+        if (tx >= a.tiles_x) break;
+        const unsigned long long mask = a.tile_masks[trow * a.tiles_x + tx];
+        if (mask != 0 || many) continue;
+        const int x_coord = tx * 8 + (lane & 7);
+        if (x_coord >= a.width || y_coord >= a.height) continue;
+        const size_t id = (size_t)y_coord * a.width + x_coord;
+        if (a.out16) {
+            uint4 px;
+            px.x = __float_as_uint((float)x_coord);
+            px.y = __float_as_uint((float)y_coord);
+            px.z = a.bg_packed;
+            px.w = 0u;
+            reinterpret_cast<uint4 *>(a.out16)[id] = px;
+        }
+        if (a.plane) a.plane[(size_t)local_row * a.width + x_coord] = a.bg_packed;
+        if (a.debug_rgb) {
+            a.debug_rgb[3 * id + 0] = a.bg_mapped[0];
+            a.debug_rgb[3 * id + 1] = a.bg_mapped[1];
+            a.debug_rgb[3 * id + 2] = a.bg_mapped[2];
+        }
+    }
+}
+
+template <int V>
+RPT_DEV void render_binned_body(const KernelArgs &a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= a.main_blocks) {
+        fill_strip(a, __builtin_amdgcn_readfirstlane(((int)blockIdx.x - a.main_blocks) * 4 + wave), lane);
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 4) a.bin_counts_next[threadIdx.x] = 0;   // counters of the next frame
+    const unsigned int c0 = a.bin_counts[0], c1 = a.bin_counts[1];
+    const unsigned int stride = (unsigned int)a.main_blocks * 4u;
+    for (unsigned int g = (unsigned int)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave)); g < c0 + c1; g += stride) {
+        const unsigned int slot = g < c0 ? g : (unsigned int)a.n_tiles + (g - c0);
+        render_one_tile<V>(a, __builtin_amdgcn_readfirstlane((int)a.bin_lists[slot]), lane);
+    }
+}
+
+__global__ __launch_bounds__(256) void rpt_render_binned_v1(const KernelArgs a) { render_binned_body<1>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_binned_v1_w4(const KernelArgs a) { render_binned_body<1>(a); }
 
 // Root-side reassembly after the gather: plane of rank r, local tile k -> global tile r + k*n_ranks.
 __global__ __launch_bounds__(256) void rpt_scatter_plane_kernel(const uint32_t *planes, rpt_pixel *out16, int width,

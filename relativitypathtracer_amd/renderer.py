@@ -152,11 +152,11 @@ class Renderer:
         return list(out)
 
     def read_wave_times(self) -> np.ndarray:
-        n = ((self.width + 31) // 32) * self.local_tiles() * 4 * 2
+        n = ((self.width + 31) // 32) * self.local_tiles() * 4 * 10
         out = np.zeros(n, dtype=np.uint64)
         got = C.c_size_t()
         self._check(self._lib.rpt_read_wave_times(self._h, out.ctypes.data, n, C.byref(got)), "rpt_read_wave_times")
-        return out[:got.value].reshape(-1, 2)
+        return out[:got.value].reshape(-1, 10)
 
     def probe(self, which: int, inputs: np.ndarray, out_width: int) -> np.ndarray:
         inputs = np.ascontiguousarray(inputs, dtype=np.float32)
