@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="after timing, compare rank 0's framebuffer with the oracle on a few row bands")
     ap.add_argument("--gather", default="plane4", choices=["plane4"], help="what is gathered with N>1 (4 B/pixel colour plane)")
     args = ap.parse_args()
 
@@ -119,12 +120,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if n > 1:
+    force_dist = os.environ.get("RPT_FORCE_DIST") == "1" and "RANK" in os.environ   # rehearse the N>1 path with one rank
+    if n > 1 or force_dist:
         import torch.distributed as td
         td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     W, H = args.width, args.height
-    scene_name, vel, t = WORLDS = WORKLOADS[args.workload]
+    scene_name, vel, t = WORKLOADS[args.workload]
     scene = Scene.from_file(scene_name)
     scene.set_camera(vel, t)
     scene.update_objects()
@@ -136,7 +138,7 @@ def main():
     r.upload_scene(scene)
     r.set_scene_params(scene, W, H)
     r.set_variant(args.variant)
-    frame = rdist.FrameSharder(r, W, H, rank, n)   # allocates outputs; N == 1 renders straight into the framebuffer
+    frame = rdist.FrameSharder(r, W, H, rank, n, force_gather=force_dist)   # allocates outputs; N == 1 renders straight into the framebuffer
 
     def step():
         r.set_objects(scene)            # per-frame Object[] refresh, as the reference does
@@ -174,7 +176,7 @@ def main():
         mrays = W * H / (ms_per_step * 1e-3) / 1e6
         # roofline of the dominant kernel (the render kernel): algorithmic bytes one launch moves on this
         # rank / its mean duration.  With N ranks one launch covers 1/N of the pixels (4 B/px plane).
-        if n == 1:
+        if n == 1 and not force_dist:
             alg = algorithmic_bytes(W, H, n_objects)
         else:
             alg = 4 * W * frame.local_rows + 320 * n_objects
@@ -200,8 +202,17 @@ def main():
         }
         if not args.no_cpu_baseline and n == 1:
             out["cpu_baseline"] = cpu_baseline(scene, W, H)
+        if args.check:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_ffi
+            fb = frame.framebuffer.cpu().numpy().view(np.uint8).reshape(H, W, 16)
+            ok = True
+            for (r0, r1) in [(0, 8), (H * 2 // 5, H * 2 // 5 + 16), (H // 2, H // 2 + 16), (H - 8, H)]:
+                opx, _, _ = oracle_ffi.render(scene, W, H, rows=(r0, r1), want_rgb=False)
+                ok = ok and np.array_equal(fb[r0:r1, :, 8:12], opx["rgba"].reshape(H, W, 4)[r0:r1])
+            out["check"] = "framebuffer rows identical to the oracle" if ok else "MISMATCH vs oracle"
         print(json.dumps(out), flush=True)
-    if n > 1:
+    if n > 1 or force_dist:
         td.barrier()
         td.destroy_process_group()
     r.close()

@@ -15,6 +15,8 @@
 
 #pragma clang fp contract(off)
 
+#define RPT_STAGING_SLOTS 4
+
 namespace {
 
 struct DeviceBuffer {
@@ -44,8 +46,10 @@ struct rpt_ctx {
     DeviceBuffer dnodes, dtris, dobjs;        // derived layouts (rpt_kernels.hip.h)
     bool compact_ok = false;                  // derived octree layout usable (children consecutive)
     DeviceBuffer owned_out, owned_plane, owned_rgb;
-    void *pinned_objects = nullptr;
+    void *pinned_objects = nullptr;                   // RPT_STAGING_SLOTS pinned slots of Object[] + DObj[]
     size_t pinned_capacity = 0;
+    hipEvent_t staging_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned int staging_used = 0, staging_next = 0;
     int object_count = 0;
     size_t vertex_count = 0, normal_count = 0, uv_count = 0, triangle_words = 0, octree_count = 0, octree_tri_count = 0;
     bool scene_uploaded = false;
@@ -316,7 +320,7 @@ int launch(rpt_ctx *ctx) {
     std::memset(&a, 0, sizeof a);
     a.dnodes = (const rptd::DNode *)ctx->dnodes.ptr;
     a.dtris = (const rptd::DTri *)ctx->dtris.ptr;
-    a.dobjs = (const rptd::DObj *)ctx->dobjs.ptr;
+    a.dobjs = (const rptd::DObj *)((const char *)ctx->objects.ptr + (size_t)ctx->object_count * sizeof(rpt_object));
     a.objects = (const rpt_object *)ctx->objects.ptr;
     a.vertices = (const rpt_float3 *)ctx->vertices.ptr;
     a.normals = (const rpt_float3 *)ctx->normals.ptr;
@@ -472,6 +476,7 @@ void rpt_destroy(rpt_ctx *ctx) {
                             &ctx->octreeTris, &ctx->textures, &ctx->dnodes, &ctx->dtris, &ctx->dobjs, &ctx->counters, &ctx->wave_times, &ctx->tile_masks, &ctx->bin_counts, &ctx->bin_lists, &ctx->owned_out, &ctx->owned_plane, &ctx->owned_rgb})
         release(*b);
     if (ctx->pinned_objects) (void)hipHostFree(ctx->pinned_objects);
+    for (hipEvent_t e : ctx->staging_done) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     for (hipEvent_t e : ctx->timing_events) (void)hipEventDestroy(e);
@@ -526,24 +531,34 @@ int rpt_set_objects(rpt_ctx *ctx, const void *objects, int count) {
     if (int rc = validate_objects(ctx, (const rpt_object *)objects, count)) return rc;
     const size_t bytes = (size_t)count * sizeof(rpt_object);
     const size_t dbytes = (size_t)count * sizeof(rptd::DObj);
-    if (bytes + dbytes > ctx->pinned_capacity) {
+    // staging ring of pinned slots: the copy of frame k may still be in flight when frame k+1 is staged, so
+    // each slot has an event and is reused only once its own transfer has completed (no per-frame stream sync)
+    const size_t slot_bytes = ((bytes + dbytes + 255) / 256) * 256;
+    if (slot_bytes * RPT_STAGING_SLOTS > ctx->pinned_capacity) {
+        RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->pinned_objects) RPT_HIP(ctx, hipHostFree(ctx->pinned_objects));
         ctx->pinned_objects = nullptr;
         ctx->pinned_capacity = 0;
-        const size_t cap = (bytes + dbytes) < 4096 ? 4096 : (bytes + dbytes) * 2;
+        const size_t cap = (slot_bytes < 4096 ? 4096 : slot_bytes * 2) * RPT_STAGING_SLOTS;
         RPT_HIP(ctx, hipHostMalloc(&ctx->pinned_objects, cap, hipHostMallocDefault));
         ctx->pinned_capacity = cap;
+        for (int k = 0; k < RPT_STAGING_SLOTS; k++)
+            if (!ctx->staging_done[k]) RPT_HIP(ctx, hipEventCreateWithFlags(&ctx->staging_done[k], hipEventDisableTiming));
+        ctx->staging_used = 0;
     }
-    if (bytes > ctx->objects.capacity || dbytes > ctx->dobjs.capacity) RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (int rc = reserve(ctx, ctx->objects, bytes)) return rc;
-    if (int rc = reserve(ctx, ctx->dobjs, dbytes)) return rc;
+    // Object[] and DObj[] live back to back in one device buffer: one transfer per frame
+    if (bytes + dbytes > ctx->objects.capacity) RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = reserve(ctx, ctx->objects, bytes + dbytes)) return rc;
     if (bytes) {
-        // the staging copy must not be overwritten while a previous frame's transfer is in flight
-        RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        std::memcpy(ctx->pinned_objects, objects, bytes);
-        build_dobjs(ctx, (const rpt_object *)objects, count, (rptd::DObj *)((char *)ctx->pinned_objects + bytes));
-        RPT_HIP(ctx, hipMemcpyAsync(ctx->objects.ptr, ctx->pinned_objects, bytes, hipMemcpyHostToDevice, ctx->stream));
-        RPT_HIP(ctx, hipMemcpyAsync(ctx->dobjs.ptr, (char *)ctx->pinned_objects + bytes, dbytes, hipMemcpyHostToDevice, ctx->stream));
+        const int k = (int)(ctx->staging_next % RPT_STAGING_SLOTS);
+        if (ctx->staging_used & (1u << k)) RPT_HIP(ctx, hipEventSynchronize(ctx->staging_done[k]));
+        char *slot = (char *)ctx->pinned_objects + (ctx->pinned_capacity / RPT_STAGING_SLOTS) * k;
+        std::memcpy(slot, objects, bytes);
+        build_dobjs(ctx, (const rpt_object *)objects, count, (rptd::DObj *)(slot + bytes));
+        RPT_HIP(ctx, hipMemcpyAsync(ctx->objects.ptr, slot, bytes + dbytes, hipMemcpyHostToDevice, ctx->stream));
+        RPT_HIP(ctx, hipEventRecord(ctx->staging_done[k], ctx->stream));
+        ctx->staging_used |= 1u << k;
+        ctx->staging_next++;
     }
     ctx->object_count = count;
     ctx->host_objects.assign((const uint8_t *)objects, (const uint8_t *)objects + bytes);

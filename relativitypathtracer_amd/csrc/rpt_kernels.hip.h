@@ -187,7 +187,7 @@ RPT_DEV int getOppositeBoxSide(const ExitPlan &p, f3 &uv) {
 RPT_DEV int octree_child_step(f3 &uv);
 RPT_DEV int octree_child_step_fast(f3 &uv) {
     const unsigned int lim = 0x3FC00000u;   // 1.5f
-    const bool in_range = (__float_as_uint(uv.x) < lim) & (__float_as_uint(uv.y) < lim) & (__float_as_uint(uv.z) < lim);
+    const bool in_range = (__float_as_uint(uv.x) < lim) && (__float_as_uint(uv.y) < lim) && (__float_as_uint(uv.z) < lim);
     if (!in_range) return octree_child_step(uv);
     const float top = 1.0f - RPT_EPSILON;
     const bool bx = uv.x >= 0.5f, by = uv.y >= 0.5f, bz = uv.z >= 0.5f;

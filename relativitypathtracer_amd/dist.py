@@ -74,13 +74,14 @@ def reassemble_planes(planes: np.ndarray, width: int, height: int, world: int) -
 class FrameSharder:
     """Owns the output tensors of one rank and runs render (+ gather + scatter) for one frame."""
 
-    def __init__(self, renderer, width: int, height: int, rank: int, world: int):
+    def __init__(self, renderer, width: int, height: int, rank: int, world: int, force_gather: bool = False):
         import torch
         self.r, self.W, self.H, self.rank, self.world = renderer, width, height, rank, world
         dev = torch.device("cuda", torch.cuda.current_device())
         self.framebuffer: Optional["torch.Tensor"] = None
         self.local_rows = local_tile_count(height, rank, world) * TILE_ROWS
-        if world == 1:
+        self.exchange = world > 1 or force_gather      # force_gather: run the plane/gather/scatter path with one rank
+        if not self.exchange:
             renderer.set_rows(0, 1, False)
             self.framebuffer = torch.zeros(width * height * 4, dtype=torch.int32, device=dev)
             renderer.set_output(self.framebuffer.data_ptr())
@@ -98,7 +99,7 @@ class FrameSharder:
 
     def render_and_gather(self):
         self.r.render_async()
-        if self.world > 1:
+        if self.exchange:
             import torch.distributed as td
             td.gather(self.plane, list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0)
             if self.rank == 0:
