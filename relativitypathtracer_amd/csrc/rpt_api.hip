@@ -5,7 +5,9 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <utility>
 #include <vector>
@@ -36,6 +38,11 @@ struct rpt_ctx {
 
     DeviceBuffer objects, vertices, normals, uvs, triangles, octrees, octreeTris, textures;
     DeviceBuffer counters, wave_times;
+    DeviceBuffer row_cost;                            // per tile row: two alternating arrays of cycle counts
+    unsigned int *host_row_cost = nullptr;            // pinned read-back of an earlier frame's row costs
+    size_t host_row_cost_rows = 0;
+    long long row_cost_config = -1;
+    unsigned int row_parity = 0;
     unsigned int *host_counts = nullptr;              // pinned read-back of the tile-class counters (grid-size estimate)
     long long counts_config = -1;                     // configuration the read-back belongs to
     unsigned int scene_epoch = 0;                     // bumped by rpt_upload_scene / rpt_set_params
@@ -356,6 +363,37 @@ int launch(rpt_ctx *ctx) {
     const int tiles = local_tile_count(ctx);
     if (tiles == 0) return RPT_OK;
     const dim3 grid((ctx->width + 31) / 32, tiles);
+    // dispatch-order hint (variant 17 only): dearest tile rows first
+    unsigned int *row_cost_dev = nullptr;
+    rptd::RowOrder order;
+    bool use_row_order = false;
+    if (ctx->variant == 17 && tiles <= 1024) {
+        const long long config = ((long long)ctx->scene_epoch << 40) | ((long long)tiles << 12) | (long long)(ctx->first_tile & 0xfff);
+        if ((size_t)tiles * 8 > ctx->row_cost.capacity || !ctx->host_row_cost || ctx->host_row_cost_rows < (size_t)tiles) {
+            RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (int rc = reserve(ctx, ctx->row_cost, (size_t)tiles * 8)) return rc;
+            if (ctx->host_row_cost) RPT_HIP(ctx, hipHostFree(ctx->host_row_cost));
+            RPT_HIP(ctx, hipHostMalloc((void **)&ctx->host_row_cost, (size_t)tiles * 4, hipHostMallocDefault));
+            ctx->host_row_cost_rows = (size_t)tiles;
+            ctx->row_cost_config = -1;
+        }
+        if (ctx->row_cost_config != config) {          // new configuration: forget what was measured
+            RPT_HIP(ctx, hipMemsetAsync(ctx->row_cost.ptr, 0, (size_t)tiles * 8, ctx->stream));
+            std::memset(ctx->host_row_cost, 0, (size_t)tiles * 4);
+            ctx->row_cost_config = config;
+        }
+        // order from the (possibly stale) read-back, dearest rows first; all zero -> natural order
+        unsigned int cmax = 0;
+        for (int r = 0; r < tiles; r++) cmax = ctx->host_row_cost[r] > cmax ? ctx->host_row_cost[r] : cmax;
+        use_row_order = cmax != 0;
+        std::vector<std::pair<unsigned int, int>> keyed((size_t)tiles);
+        for (int r = 0; r < tiles; r++) keyed[r] = {ctx->host_row_cost[r], r};
+        if (cmax != 0)
+            std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<unsigned int, int> &x, const std::pair<unsigned int, int> &y) { return x.first > y.first; });
+        for (int r = 0; r < tiles; r++) order.row[r] = (unsigned short)keyed[r].second;
+        row_cost_dev = (unsigned int *)ctx->row_cost.ptr + (size_t)tiles * (ctx->row_parity & 1);
+        a.row_cost = row_cost_dev;
+    }
     // variant 0 = default: the derived-layout kernel when the octree allows it, else the general one; with
     // several objects the tile-binned form (per-tile object masks) wins by a large factor, with two or three
     // the plain per-pixel loop is as fast (measured: DESIGN.md §6)
@@ -431,6 +469,7 @@ int launch(rpt_ctx *ctx) {
     }
     case 15: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_pipe, grid, dim3(256), 0, ctx->stream, a); break;
     case 16: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_pipe_w4, grid, dim3(256), 0, ctx->stream, a); break;
+    case 17: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_ordered, grid, dim3(256), 0, ctx->stream, a, order); break;
     case 14: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_prio, grid, dim3(256), 0, ctx->stream, a); break;
     case 8: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only, grid, dim3(256), 0, ctx->stream, a); break;
     case 9: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only_w6, grid, dim3(256), 0, ctx->stream, a); break;
@@ -438,6 +477,14 @@ int launch(rpt_ctx *ctx) {
     default: return fail(ctx, RPT_ERR_ARG, "unknown kernel variant");
     }
     RPT_HIP(ctx, hipGetLastError());
+    (void)use_row_order;
+    if (row_cost_dev && v == 17) {
+        // read this frame's row costs back without a sync (the host looks at them some frames later) and
+        // clear the other array for the next frame
+        RPT_HIP(ctx, hipMemcpyAsync(ctx->host_row_cost, row_cost_dev, (size_t)tiles * 4, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->row_parity++;
+        RPT_HIP(ctx, hipMemsetAsync((unsigned int *)ctx->row_cost.ptr + (size_t)tiles * (ctx->row_parity & 1), 0, (size_t)tiles * 4, ctx->stream));
+    }
     return RPT_OK;
 }
 
@@ -472,8 +519,9 @@ void rpt_destroy(rpt_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->host_counts) (void)hipHostFree(ctx->host_counts);
+    if (ctx->host_row_cost) (void)hipHostFree(ctx->host_row_cost);
     for (DeviceBuffer *b : {&ctx->objects, &ctx->vertices, &ctx->normals, &ctx->uvs, &ctx->triangles, &ctx->octrees,
-                            &ctx->octreeTris, &ctx->textures, &ctx->dnodes, &ctx->dtris, &ctx->dobjs, &ctx->counters, &ctx->wave_times, &ctx->tile_masks, &ctx->bin_counts, &ctx->bin_lists, &ctx->owned_out, &ctx->owned_plane, &ctx->owned_rgb})
+                            &ctx->octreeTris, &ctx->textures, &ctx->dnodes, &ctx->dtris, &ctx->dobjs, &ctx->counters, &ctx->wave_times, &ctx->tile_masks, &ctx->bin_counts, &ctx->bin_lists, &ctx->row_cost, &ctx->owned_out, &ctx->owned_plane, &ctx->owned_rgb})
         release(*b);
     if (ctx->pinned_objects) (void)hipHostFree(ctx->pinned_objects);
     for (hipEvent_t e : ctx->staging_done) if (e) (void)hipEventDestroy(e);
@@ -613,7 +661,7 @@ int rpt_set_debug_rgb(rpt_ctx *ctx, void *p) {
 }
 
 int rpt_set_variant(rpt_ctx *ctx, int variant) {
-    if (!ctx || variant < 0 || variant > 16) return RPT_ERR_ARG;
+    if (!ctx || variant < 0 || variant > 17) return RPT_ERR_ARG;
     ctx->variant = variant;
     return RPT_OK;
 }
@@ -728,7 +776,10 @@ int rpt_last_frame_ms(rpt_ctx *ctx, float *ms) {
 int rpt_timed_frames(rpt_ctx *ctx, int frames, float *avg_ms) {
     if (!ctx || frames <= 0 || !avg_ms) return RPT_ERR_ARG;
     RPT_HIP(ctx, hipSetDevice(ctx->device));
-    if (int rc = launch(ctx)) return rc;   // untimed: allocates outputs, warms caches
+    for (int w = 0; w < 2; w++) {          // untimed: allocate outputs, warm caches, measure the row costs
+        if (int rc = launch(ctx)) return rc;
+        RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     RPT_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     for (int i = 0; i < frames; i++)
         if (int rc = launch(ctx)) return rc;

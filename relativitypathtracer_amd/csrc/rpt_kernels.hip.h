@@ -89,9 +89,15 @@ struct KernelArgs {
     unsigned int *bin_counts;                // [4] tiles with a mesh candidate / analytic candidates only / none
     unsigned int *bin_counts_next;           // the other buffer of the pair, zeroed by the main kernel for the next frame
     int main_blocks;                         // blocks of the binned kernel that walk the tile lists
+    // dispatch-order hint (any permutation is correct): tile row handled by blockIdx.y, dearest rows first, from
+    // the per-row cycle counts an earlier frame accumulated in row_cost (long octree-walk waves start at t = 0
+    // and the cheap rows fill the tail).  In the kernel-argument segment so it costs no dependent load.
+    unsigned int *row_cost;                  // [n local tile rows] accumulated wave cycles >> 10 (this frame)
     unsigned int *bin_lists;                 // [3][n_tiles] tile ids per class
     unsigned long long mesh_object_bits;     // which of the first 64 objects are meshes
 };
+
+struct RowOrder { unsigned short row[1024]; };   // second kernel argument of the row-ordered variant only
 
 struct Hit {                 // opencl_kernel.cl:38-44
     float dist;
@@ -827,7 +833,7 @@ RPT_DEV uint32_t tonemap_pack(const KernelArgs &a, f3 color, f3 &mapped) {
 //   V = 0: reads the reference layouts only (general fallback, any valid octree)
 //   V = 1: derived DNode/DTri/DObj layouts
 template <int V>
-RPT_DEV void render_pixel_body(const KernelArgs &a) {
+RPT_DEV void render_pixel_body(const KernelArgs &a, const RowOrder *order = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     unsigned long long t_start = 0;
@@ -836,9 +842,11 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
         if ((threadIdx.x & 63) < 8) rpt_diag_lds[threadIdx.x >> 6][threadIdx.x & 63] = 0;
         rpt_diag_lds[threadIdx.x >> 6][6] = clock64();
     }
+    const unsigned long long c_start = (V == 7 && a.row_cost) ? (unsigned long long)clock64() : 0ull;
+    const int tile_row = (V == 7 && order) ? (int)order->row[blockIdx.y] : (int)blockIdx.y;
     const int x_coord = blockIdx.x * 32 + wave * 8 + (lane & 7);
-    const int local_row = blockIdx.y * RPT_TILE_ROWS + (lane >> 3);
-    const int y_coord = (a.first_tile + (int)blockIdx.y * a.tile_step) * RPT_TILE_ROWS + (lane >> 3);
+    const int local_row = tile_row * RPT_TILE_ROWS + (lane >> 3);
+    const int y_coord = (a.first_tile + tile_row * a.tile_step) * RPT_TILE_ROWS + (lane >> 3);
     if (x_coord >= a.width || y_coord >= a.height) return;   // the reference has no guard (UB)
 
     const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);
@@ -861,6 +869,11 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
         a.debug_rgb[3 * id + 0] = mapped.x;
         a.debug_rgb[3 * id + 1] = mapped.y;
         a.debug_rgb[3 * id + 2] = mapped.z;
+    }
+    if (V == 7 && a.row_cost) {   // feed the next frames' dispatch order: only waves that were expensive report
+        const unsigned long long cyc = (unsigned long long)clock64() - c_start;
+        const unsigned long long m = __ballot(1);
+        if (cyc > 16384ull && lane == __ffsll((long long)m) - 1) atomicAdd(&a.row_cost[tile_row], (unsigned int)(cyc >> 10));
     }
     if (V == 4 && a.wave_times) {
         const unsigned long long t_end = wall_clock64();
@@ -886,6 +899,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_prio(const KernelArgs a) { render_pixel_body<5>(a); }
 __global__ __launch_bounds__(256) void rpt_render_kernel_v1_pipe(const KernelArgs a) { render_pixel_body<6>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_pipe_w4(const KernelArgs a) { render_pixel_body<6>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_ordered(const KernelArgs a, const RowOrder o) { render_pixel_body<7>(a, &o); }
 __global__ __launch_bounds__(256) void rpt_render_kernel_primary_only(const KernelArgs a) { render_pixel_body<3>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_primary_only_w6(const KernelArgs a) { render_pixel_body<3>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_primary_only_w8(const KernelArgs a) { render_pixel_body<3>(a); }
