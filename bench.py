@@ -196,10 +196,20 @@ def main():
             "kernel_ms": round(kernel_ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "rpt_render_kernel", "algorithmic_bytes_per_launch": alg,
+                         "kernel": "rpt_render_kernel_v1_w4", "algorithmic_bytes_per_launch": alg,
                          "note": "16 B/pixel written + 320 B/object read per launch (SURVEY.md §8d); the path is "
                                  "latency/VALU-bound by construction, HBM fraction reported because it is the contract"},
         }
+        # HBM traffic of the same launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
+        # WRITE_SIZE, MI355X_MICROARCH.md §HBM); PMC cannot be collected from inside this process
+        prof = os.path.join(ROOT, "profiles", "r01_final_bunny4k_pmc_summary.json")
+        if (args.workload, W, H, n, args.variant) == ("bunny", 3840, 2160, 1, 0) and not force_dist and os.path.exists(prof):
+            try:
+                d = json.load(open(prof))["derived"]
+                out["roofline"]["traffic"] = int(sum(v for k, v in d.items() if k.startswith("hbm_")))
+                out["roofline"]["traffic_source"] = "profiles/r01_final_bunny4k_pmc_summary.json (rocprofv3 --pmc, same command)"
+            except Exception:
+                pass
         if not args.no_cpu_baseline and n == 1:
             out["cpu_baseline"] = cpu_baseline(scene, W, H)
         if args.check:
