@@ -1,0 +1,108 @@
+"""Randomised scenes through the DSL -> HIP path vs oracle, bit-exact (textured spheres: 1e-4 / 1 LSB).
+
+Covers what the shipped scenes do not: several lights, lights that move, textured meshes (pear.obj has vt),
+textured and flashing objects with velocities, objects around and behind the camera, the camera inside a
+cube / a mesh's bounding box, rotated and non-uniformly scaled meshes, two meshes in one scene (the second
+root's triangle list contains the first mesh's triangles — the reference's quirk), interval 0 with lights.
+"""
+import numpy as np
+import pytest
+
+import oracle_ffi
+from relativitypathtracer_amd import Scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    from relativitypathtracer_amd.renderer import Renderer
+    r = Renderer(0)
+    yield r
+    r.close()
+
+
+def random_scene_text(rng):
+    lines = []
+    meshes = []
+    if rng.random() < 0.7:
+        meshes.append(rng.choice(["Models/pear.obj", "Models/bunny.obj", "Models/cube.obj", "Models/triangle.obj"]))
+        if rng.random() < 0.3:
+            meshes.append(rng.choice(["Models/cube.obj", "Models/pear.obj"]))
+    for m in meshes:
+        lines.append("M" + m)
+    textures = []
+    for t in ["Textures/box.jpg", "Textures/tile.jpg", "Textures/meterstick.png", "Textures/soccer.jpg"]:
+        if rng.random() < 0.4:
+            textures.append(t)
+            lines.append("T" + t)
+    n_obj = int(rng.integers(1, 9))
+    has_textured_sphere = False
+    for k in range(n_obj):
+        kind = rng.choice(["s", "c", "m"] if meshes else ["s", "c"], p=[0.3, 0.4, 0.3] if meshes else [0.45, 0.55])
+        if kind == "m":
+            mi = int(rng.integers(0, len(meshes)))
+            lines.append(f"Om{mi}")
+            scale = float(rng.choice([1.0, 2.0, 12.0])) if "bunny" in meshes[mi] else float(rng.uniform(0.5, 2.0))
+        else:
+            lines.append("O" + kind)
+            scale = float(rng.uniform(0.3, 2.5))
+        pos = rng.uniform([-6, -4, -3], [6, 4, 14])
+        if rng.random() < 0.1:
+            pos = rng.uniform(-0.3, 0.3, size=3)          # camera inside / touching the object
+        ang = float(rng.choice([0.0, rng.uniform(-3, 3)]))
+        axis = rng.normal(size=3)
+        sc = scale * rng.uniform(0.5, 1.5, size=3) if rng.random() < 0.5 else np.full(3, scale)
+        lines.append(" p" + ",".join(f"{v:.4f}" for v in [*pos, ang, *axis, *sc]))
+        lines.append(" c" + ",".join(f"{v:.3f}" for v in rng.uniform(0.05, 1.5, size=3)))
+        if textures and rng.random() < 0.5:
+            lines.append(f" t{int(rng.integers(0, len(textures)))}")
+            has_textured_sphere = has_textured_sphere or kind == "s"
+        if rng.random() < 0.3:
+            lines.append(" l1")
+        if rng.random() < 0.35:
+            v = rng.normal(size=3)
+            v = v / np.linalg.norm(v) * rng.choice([0.2, 0.6, 0.9, 0.97])
+            lines.append(" v" + ",".join(f"{c:.5f}" for c in v))
+        if rng.random() < 0.25:
+            lines.append(f" f{rng.uniform(0.5, 3):.3f},{rng.uniform(0.1, 1.5):.3f}")
+    lines.append(f"A{rng.uniform(0, 1):.3f}")
+    if rng.random() < 0.5:
+        lines.append("W" + ",".join(f"{v:.2f}" for v in rng.uniform(0.5, 6, size=3)))
+    if rng.random() < 0.25:
+        lines.append("I")
+    lines.append("R")
+    return "\n".join(lines) + "\n", has_textured_sphere
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_scene(renderer, seed):
+    rng = np.random.default_rng(1000 + seed)
+    text, approx = random_scene_text(rng)
+    scene = Scene()
+    scene.inputScene(text)
+    v = rng.normal(size=3)
+    v = v / np.linalg.norm(v) * rng.choice([0.0, 0.0, 0.5, 0.95])
+    scene.set_camera(tuple(float(c) for c in v), float(rng.uniform(-3, 20)))
+    scene.update_objects()
+    W, H = [(320, 184), (256, 144), (200, 150)][seed % 3]
+    opx, orgb, _ = oracle_ffi.render(scene, W, H)
+    for variant in (0, 1, 13):                      # default, reference-layout kernel, tile-binned kernel
+        renderer.set_variant(variant)
+        renderer.upload_scene(scene)
+        renderer.set_scene_params(scene, W, H)
+        renderer.set_rows(0, 1, False)
+        renderer.set_output(None)
+        renderer.set_debug_rgb(True)
+        renderer.render()
+        px, rgb = renderer.read_framebuffer(), renderer.read_debug_rgb()
+        finite = np.isfinite(orgb)
+        assert np.array_equal(np.isfinite(rgb), finite)
+        err = float(np.max(np.abs(rgb[finite] - orgb[finite]))) if finite.any() else 0.0
+        assert err <= 1e-4, f"seed {seed} variant {variant}: max |rgb - oracle| = {err}\n{text}"
+        if approx:
+            d = np.abs(px["rgba"].astype(np.int16) - opx["rgba"].astype(np.int16))
+            assert d.max() <= 1
+        else:
+            assert np.array_equal(rgb.view(np.uint32), orgb.view(np.uint32)), f"seed {seed} variant {variant}: float RGB not bit-identical\n{text}"
+            assert np.array_equal(px["rgba"], opx["rgba"]), f"seed {seed} variant {variant}: packed bytes differ\n{text}"
