@@ -118,8 +118,10 @@ int rpt_scatter_colour_plane(rpt_ctx *ctx, const void *planes, void *out16, int 
 
 /* Diagnostic variant 7 only: loop-iteration counters of the octree walk of the last frame —
  * [0..2] leaf steps / triangle tests / descent steps summed over lanes, [3..5] the same counted
- * once per executing wavefront (lane sum / (64 * wave count) = SIMD utilisation of that loop). */
-int rpt_read_counters(rpt_ctx *ctx, unsigned long long out[8]);
+ * once per executing wavefront (lane sum / (64 * wave count) = SIMD utilisation of that loop); [6] longest walk,
+ * [7] walks > 32 steps, [8] sum over leaf steps of distinct nodes among the active lanes, [9] sum of active lanes,
+ * [10..15] histogram of distinct nodes per step (1, 2, 3-4, 5-8, 9-16, >16). */
+int rpt_read_counters(rpt_ctx *ctx, unsigned long long out[16]);
 
 /* Diagnostic variant 7 only: per-wavefront {start, end} stamps (100 MHz s_memrealtime) of the last
  * frame, wave w = (blockIdx.y*gridDim.x + blockIdx.x)*4 + wave-in-block. */

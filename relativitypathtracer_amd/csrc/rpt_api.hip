@@ -413,8 +413,8 @@ int launch(rpt_ctx *ctx) {
     case 5: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_w6, grid, dim3(256), 0, ctx->stream, a); break;
     case 6: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_w8, grid, dim3(256), 0, ctx->stream, a); break;
     case 7:
-        if (int rc = reserve(ctx, ctx->counters, 8 * sizeof(unsigned long long))) return rc;
-        RPT_HIP(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        if (int rc = reserve(ctx, ctx->counters, 16 * sizeof(unsigned long long))) return rc;
+        RPT_HIP(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 16 * sizeof(unsigned long long), ctx->stream));
         a.counters = (unsigned long long *)ctx->counters.ptr;
         hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_diag, grid, dim3(256), 0, ctx->stream, a);
         break;
@@ -470,6 +470,10 @@ int launch(rpt_ctx *ctx) {
     case 15: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_pipe, grid, dim3(256), 0, ctx->stream, a); break;
     case 16: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_pipe_w4, grid, dim3(256), 0, ctx->stream, a); break;
     case 17: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_ordered, grid, dim3(256), 0, ctx->stream, a, order); break;
+    case 18: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_packet, grid, dim3(256), 0, ctx->stream, a); break;
+    case 19: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_packet_w4, grid, dim3(256), 0, ctx->stream, a); break;
+    case 20: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_half, dim3(grid.x, grid.y * 2), dim3(256), 0, ctx->stream, a); break;
+    case 21: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_quarter, dim3((ctx->width + 15) / 16, grid.y * 2), dim3(256), 0, ctx->stream, a); break;
     case 14: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_prio, grid, dim3(256), 0, ctx->stream, a); break;
     case 8: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only, grid, dim3(256), 0, ctx->stream, a); break;
     case 9: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only_w6, grid, dim3(256), 0, ctx->stream, a); break;
@@ -661,7 +665,7 @@ int rpt_set_debug_rgb(rpt_ctx *ctx, void *p) {
 }
 
 int rpt_set_variant(rpt_ctx *ctx, int variant) {
-    if (!ctx || variant < 0 || variant > 17) return RPT_ERR_ARG;
+    if (!ctx || variant < 0 || variant > 21) return RPT_ERR_ARG;
     ctx->variant = variant;
     return RPT_OK;
 }
@@ -807,12 +811,12 @@ int rpt_scatter_colour_plane(rpt_ctx *ctx, const void *planes, void *out16, int 
     return RPT_OK;
 }
 
-int rpt_read_counters(rpt_ctx *ctx, unsigned long long out[8]) {
+int rpt_read_counters(rpt_ctx *ctx, unsigned long long out[16]) {
     if (!ctx || !out) return RPT_ERR_ARG;
     if (!ctx->counters.ptr) return fail(ctx, RPT_ERR_STATE, "rpt_read_counters: render with the diagnostic variant (7) first");
     RPT_HIP(ctx, hipSetDevice(ctx->device));
     RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    RPT_HIP(ctx, hipMemcpy(out, ctx->counters.ptr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    RPT_HIP(ctx, hipMemcpy(out, ctx->counters.ptr, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RPT_OK;
 }
 

@@ -343,7 +343,7 @@ RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &
     if (d.x < 0) {   // ray starts inside the root: descend to the leaf holding the origin
         uv = (newRay.origin - nmin) / (nmax - nmin);
         while (!node.is_leaf(a)) {
-            const int childIndex = octree_child_step(uv);
+            const int childIndex = V == 0 ? octree_child_step(uv) : octree_child_step_fast(uv);
             currOctreeIndex = node.child(a, childIndex);
             node.load(a, currOctreeIndex);
         }
@@ -363,6 +363,22 @@ RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &
     while (currOctreeIndex != -1) {
         if (++steps > RPT_MAX_LEAF_STEPS) break;
         count_iter<V>(a, 0);
+        if (V == 2) {   // diagnostic: how many DIFFERENT nodes do the active lanes of this wave stand in right now?
+            unsigned long long todo = __ballot(1);
+            const unsigned long long all = todo;
+            int distinct = 0;
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int n0 = __shfl(currOctreeIndex, leader);
+                todo &= ~__ballot(currOctreeIndex == n0);
+                distinct++;
+            }
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)all) - 1) {
+                atomicAdd(&a.counters[8], (unsigned long long)distinct);
+                atomicAdd(&a.counters[9], (unsigned long long)__popcll(all));
+                atomicAdd(&a.counters[10 + (distinct <= 1 ? 0 : distinct <= 2 ? 1 : distinct <= 4 ? 2 : distinct <= 8 ? 3 : distinct <= 16 ? 4 : 5)], 1ull);
+            }
+        }
         const unsigned long long t_leaf0 = diag_clock<V>();
         node.load(a, currOctreeIndex);
         nmin = node.bmin(a);
@@ -371,7 +387,7 @@ RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &
         bool descended = false;
         const unsigned long long t_desc0 = diag_clock<V>();
         while (!node.is_leaf(a)) {
-            const int childIndex = octree_child_step(uv);
+            const int childIndex = V == 0 ? octree_child_step(uv) : octree_child_step_fast(uv);
             currOctreeIndex = node.child(a, childIndex);
             node.load(a, currOctreeIndex);
             descended = true;
@@ -562,6 +578,184 @@ RPT_DEV bool octree_core_pipelined(const KernelArgs &a, const rpt_object &obj, c
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Packet walk.  Rays of one 8x8 tile are coherent: at 4K the active lanes of a wave stand in 2.4 different
+// octree nodes on average per step, and in a single node 42 % of the time (tools/divergence.py).  So the
+// walk is organised by NODE VISIT instead of by ray: each round picks the node of the first active lane;
+// if at least a quarter of the active lanes stand in that node, its 64-B record and its triangle records
+// are read ONCE through the scalar cache (SGPR operands, no per-lane loads, no max-over-lanes triangle
+// count) and all those lanes take the visit together; otherwise every active lane takes one visit of its
+// own node with vector loads.  Per ray the sequence of visits and every arithmetic operation are those of
+// octree_core (opencl_kernel.cl:200-308): only the scheduling differs.
+struct NodeData { f3 nmin, nmax; int firstChild, leafBegin, leafCount; int nb0, nb1, nb2, nb3, nb4, nb5; };
+
+struct WalkState {
+    f3 uv;
+    ExitPlan plan;
+    int idx;
+    int steps;
+    int hitTri;
+    bool active;     // still walking
+    bool arrive;     // uv is in object coordinates and must be normalised by the node it arrives at
+    bool pre;        // ray started inside the root: descending to the leaf that holds the origin
+    bool didHit;
+};
+
+RPT_DEV int pick_neighbor(const NodeData n, int side) {
+    int r = n.nb0;
+    r = side == 1 ? n.nb1 : r;
+    r = side == 2 ? n.nb2 : r;
+    r = side == 3 ? n.nb3 : r;
+    r = side == 4 ? n.nb4 : r;
+    r = side == 5 ? n.nb5 : r;
+    return r;
+}
+
+// One visit of node `n` by the calling lanes.  SCALAR: the triangle records are read with a wave-uniform
+// index (one scalar-cache read per record for the whole group); otherwise per lane.
+template <bool SCALAR>
+RPT_DEV void visit_node(const KernelArgs &a, const NodeData n, const Ray &ray, WalkState &st, Hit &hit) {
+    if (st.arrive) st.uv = (st.uv - n.nmin) / (n.nmax - n.nmin);
+    if (n.firstChild != -1) {
+        st.idx = n.firstChild + octree_child_step_fast(st.uv);
+        st.arrive = false;
+        return;
+    }
+    if (st.pre) {   // the leaf that holds the origin: the walk proper starts from its entry point (opencl_kernel.cl:242-251)
+        f2 d;
+        int cs, fs;
+        if (!intersect_AABB(n.nmin, n.nmax, ray, d, cs, fs)) {
+            st.active = false;
+            return;
+        }
+        st.uv = ray.origin + ray.dir * d.x;
+        st.plan = makeExitPlan(normalize(ray.dir / (n.nmax - n.nmin)));
+        st.pre = false;
+        st.arrive = true;      // same node again: next visit normalises uv and handles it as a leaf
+        return;
+    }
+    if (++st.steps > RPT_MAX_LEAF_STEPS) {
+        st.active = false;
+        return;
+    }
+    const int kend = n.leafBegin + n.leafCount;
+    for (int k = n.leafBegin; k < kend; k++) {
+        f3 A, v0v1, v0v2;
+        int tri;
+        if (SCALAR) {
+            const DTri &t = a.dtris[k];
+            A = mk3(t.ax, t.ay, t.az);
+            v0v1 = mk3(t.e1x, t.e1y, t.e1z);
+            v0v2 = mk3(t.e2x, t.e2y, t.e2z);
+            tri = t.tri;
+        } else {
+            const DTriRec t = load_dtri(a, k);
+            A = t.A; v0v1 = t.v0v1; v0v2 = t.v0v2; tri = t.id;
+        }
+        float dist;
+        f2 triUV;
+        if (intersect_triangle_edges(A, v0v1, v0v2, ray, dist, triUV)) {
+            if (0 <= dist && dist < hit.dist) {
+                st.hitTri = tri;
+                hit.dist = dist;
+                hit.uv = triUV;
+                st.didHit = true;
+            }
+        }
+    }
+    const f3 extents = n.nmax - n.nmin;
+    const int farSide = getOppositeBoxSide(st.plan, st.uv);
+    st.uv = n.nmin + st.uv * extents;
+    st.idx = pick_neighbor(n, farSide);
+    st.arrive = true;
+    if (length(st.uv - ray.origin) > hit.dist) st.active = false;
+    if (st.idx == -1) st.active = false;
+}
+
+RPT_DEV NodeData node_from_record(const DNode &r) {
+    NodeData n;
+    n.nmin = mk3(r.minx, r.miny, r.minz);
+    n.nmax = mk3(r.maxx, r.maxy, r.maxz);
+    n.firstChild = r.firstChild;
+    n.leafBegin = r.leafBegin;
+    n.leafCount = r.leafCount;
+    n.nb0 = r.nb[0]; n.nb1 = r.nb[1]; n.nb2 = r.nb[2]; n.nb3 = r.nb[3]; n.nb4 = r.nb[4]; n.nb5 = r.nb[5];
+    return n;
+}
+
+RPT_DEV NodeData node_from_vector_load(const KernelArgs &a, int idx) {
+    NodeRef<1> r;
+    r.load(a, idx);
+    NodeData n;
+    n.nmin = r.bmin(a);
+    n.nmax = r.bmax(a);
+    n.firstChild = r.first_child();
+    n.leafBegin = r.tri_begin(a);
+    n.leafCount = r.tri_count(a);
+    n.nb0 = r.q2.y; n.nb1 = r.q2.z; n.nb2 = r.q2.w; n.nb3 = r.q3.x; n.nb4 = r.q3.y; n.nb5 = r.q3.z;
+    return n;
+}
+
+RPT_DEV bool octree_core_packet(const KernelArgs &a, const rpt_object &obj, const Ray &newRay, f3 world_origin,
+                                float world_dirlen, Hit &hit) {
+    WalkState st;
+    st.idx = obj.meshIndex;
+    st.steps = 0;
+    st.hitTri = 0;
+    st.didHit = false;
+    st.arrive = true;
+    st.pre = false;
+    {
+        const NodeData root = node_from_record(a.dnodes[obj.meshIndex]);     // wave-uniform index
+        f2 d;
+        int closeSide, farSide;
+        st.active = intersect_AABB(root.nmin, root.nmax, newRay, d, closeSide, farSide);
+        st.uv = newRay.origin + newRay.dir * d.x;
+        st.plan = makeExitPlan(normalize(newRay.dir / (root.nmax - root.nmin)));
+        if (st.active && d.x < 0) {     // origin inside the root: find its leaf first (uv relative to the root, no renormalisation)
+            st.uv = (newRay.origin - root.nmin) / (root.nmax - root.nmin);
+            st.pre = true;
+            st.arrive = false;
+        }
+    }
+    const bool entered = st.active;
+    while (true) {
+        const unsigned long long act = __ballot(st.active);
+        if (!act) break;
+        const int leader = __ffsll((long long)act) - 1;
+        const int n0 = __builtin_amdgcn_readlane(st.idx, leader);
+        const bool member = st.active && st.idx == n0;
+        const unsigned long long mem = __ballot(member);
+        if (4 * __popcll(mem) >= __popcll(act)) {
+            if (member) {
+                const NodeData n = node_from_record(a.dnodes[n0]);          // scalar-cache read, shared by the group
+                visit_node<true>(a, n, newRay, st, hit);
+            }
+        } else if (st.active) {
+            const NodeData n = node_from_vector_load(a, st.idx);
+            visit_node<false>(a, n, newRay, st, hit);
+        }
+    }
+    if (!entered || !st.didHit) return false;
+
+    const int hitTri = st.hitTri;
+    const float u = hit.uv.x, v = hit.uv.y;
+    const float w = 1.0f - u - v;
+    const f3 normA = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 0]]);
+    const f3 normB = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 1]]);
+    const f3 normC = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 2]]);
+    hit.normal = normalize(applyTranspose(obj.InvM, normA * w + normB * u + normC * v));
+    const rpt_float2 uvA = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 0]];
+    const rpt_float2 uvB = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 1]];
+    const rpt_float2 uvC = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 2]];
+    hit.uv.x = w * uvA.x + u * uvB.x + v * uvC.x;
+    hit.uv.y = w * uvA.y + u * uvB.y + v * uvC.y;
+    const f3 objPoint = newRay.origin + newRay.dir * hit.dist;
+    const f3 worldPoint = transformPoint(obj.M, objPoint);
+    hit.dist = length(worldPoint - world_origin) / world_dirlen;
+    return true;
+}
+
 RPT_DEV float max3(f3 v) { return cl_max(cl_max(v.x, v.y), v.z); }   // opencl_kernel.cl:310
 RPT_DEV float cube_winding(f3 origin) {
     return max3(mk3(__builtin_fabsf(origin.x), __builtin_fabsf(origin.y), __builtin_fabsf(origin.z))) < 1.0f ? -1.0f : 1.0f;
@@ -635,6 +829,7 @@ RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, H
         newRay.origin = origin;
         newRay.dir = dir;
         if (V == 6) return octree_core_pipelined(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
+        if (V == 8) return octree_core_packet(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
         return octree_core<V>(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
     }
     default:
@@ -665,6 +860,7 @@ RPT_DEV bool intersect_object_primary(const KernelArgs &a, int i, f4 rayDir, Hit
         newRay.dir = dir;
         const f3 cam3 = mk3(obj.stationaryCam.y, obj.stationaryCam.z, obj.stationaryCam.w);
         if (V == 6) return octree_core_pipelined(a, obj, newRay, cam3, length(d3), hit);
+        if (V == 8) return octree_core_packet(a, obj, newRay, cam3, length(d3), hit);
         return octree_core<V>(a, obj, newRay, cam3, length(d3), hit);
     }
     default:
@@ -832,10 +1028,15 @@ RPT_DEV uint32_t tonemap_pack(const KernelArgs &a, f3 color, f3 &mapped) {
 // One thread per pixel, wave = 8x8 tile, workgroup = 32x8 strip.
 //   V = 0: reads the reference layouts only (general fallback, any valid octree)
 //   V = 1: derived DNode/DTri/DObj layouts
-template <int V>
+// S = 0: a wave owns 8x8 pixels (all 64 lanes); S = 1: 8x4 pixels on 32 lanes; S = 2: 4x4 pixels on 16 lanes.
+// Under-filled waves trade throughput for latency: a wave's walk lasts as long as its slowest lane, so
+// fewer lanes per wave shorten the frame's critical path when there are too few pixels to fill the chip
+// (small frames, or one rank's share of a frame split over several GPUs).
+template <int V, int S = 0>
 RPT_DEV void render_pixel_body(const KernelArgs &a, const RowOrder *order = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    if (S > 0 && lane >= (64 >> S)) return;
     unsigned long long t_start = 0;
     if (V == 4) {
         t_start = wall_clock64();
@@ -843,10 +1044,13 @@ RPT_DEV void render_pixel_body(const KernelArgs &a, const RowOrder *order = null
         rpt_diag_lds[threadIdx.x >> 6][6] = clock64();
     }
     const unsigned long long c_start = (V == 7 && a.row_cost) ? (unsigned long long)clock64() : 0ull;
-    const int tile_row = (V == 7 && order) ? (int)order->row[blockIdx.y] : (int)blockIdx.y;
-    const int x_coord = blockIdx.x * 32 + wave * 8 + (lane & 7);
-    const int local_row = tile_row * RPT_TILE_ROWS + (lane >> 3);
-    const int y_coord = (a.first_tile + tile_row * a.tile_step) * RPT_TILE_ROWS + (lane >> 3);
+    // blockIdx.y counts bands of (8 >> (S ? 1 : 0)) rows inside the 8-row tiles of this context
+    const int band = (int)blockIdx.y;
+    const int tile_row = (V == 7 && order) ? (int)order->row[band] : (S ? band >> 1 : band);
+    const int row_in_tile = S ? ((band & 1) * 4 + (S == 1 ? (lane >> 3) : (lane >> 2))) : (lane >> 3);
+    const int x_coord = S == 2 ? ((int)blockIdx.x * 16 + wave * 4 + (lane & 3)) : ((int)blockIdx.x * 32 + wave * 8 + (lane & 7));
+    const int local_row = tile_row * RPT_TILE_ROWS + row_in_tile;
+    const int y_coord = (a.first_tile + tile_row * a.tile_step) * RPT_TILE_ROWS + row_in_tile;
     if (x_coord >= a.width || y_coord >= a.height) return;   // the reference has no guard (UB)
 
     const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);
@@ -900,6 +1104,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 __global__ __launch_bounds__(256) void rpt_render_kernel_v1_pipe(const KernelArgs a) { render_pixel_body<6>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_pipe_w4(const KernelArgs a) { render_pixel_body<6>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_ordered(const KernelArgs a, const RowOrder o) { render_pixel_body<7>(a, &o); }
+__global__ __launch_bounds__(256) void rpt_render_kernel_v1_packet(const KernelArgs a) { render_pixel_body<8>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_packet_w4(const KernelArgs a) { render_pixel_body<8>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_half(const KernelArgs a) { render_pixel_body<1, 1>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_quarter(const KernelArgs a) { render_pixel_body<1, 2>(a); }
 __global__ __launch_bounds__(256) void rpt_render_kernel_primary_only(const KernelArgs a) { render_pixel_body<3>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_primary_only_w6(const KernelArgs a) { render_pixel_body<3>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_primary_only_w8(const KernelArgs a) { render_pixel_body<3>(a); }

@@ -147,7 +147,7 @@ class Renderer:
                     "rpt_scatter_colour_plane")
 
     def read_counters(self):
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 16)()
         self._check(self._lib.rpt_read_counters(self._h, out), "rpt_read_counters")
         return list(out)
 
