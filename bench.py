@@ -138,7 +138,7 @@ def main():
     r.upload_scene(scene)
     r.set_scene_params(scene, W, H)
     r.set_variant(args.variant)
-    frame = rdist.FrameSharder(r, W, H, rank, n, force_gather=force_dist)   # allocates outputs; N == 1 renders straight into the framebuffer
+    frame = rdist.FrameSharder(r, W, H, rank, n, force_gather=force_dist, pipeline=os.environ.get("RPT_DIST_PIPELINE", "1") != "0")   # allocates outputs; N == 1 renders straight into the framebuffer
 
     def step():
         r.set_objects(scene)            # per-frame Object[] refresh, as the reference does
@@ -190,7 +190,7 @@ def main():
             "config": {"workload": f"Scenes/{scene_name}.txt {W}x{H}, camera v={list(vel)} t={t}, interval={scene.params['interval']}, "
                                    f"mesh=Models/bunny.obj (StanfordBunny.obj is missing from the reference)" if scene_name == "bunny"
                        else f"Scenes/{scene_name}.txt {W}x{H}, camera v={list(vel)} t={t}",
-                       "frame": "rpt_set_objects + render kernel" + (" + RCCL gather(4 B/px plane) + root scatter" if n > 1 else ""),
+                       "frame": "rpt_set_objects + render kernel" + (" + RCCL gather(4 B/px plane) + root scatter, frames overlapped two deep" if n > 1 else ""),
                        "sharding": "interleaved 8-row tiles, tile k -> rank k mod N" if n > 1 else "none",
                        "variant": args.variant},
             "kernel_ms": round(kernel_ms, 4),

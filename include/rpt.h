@@ -115,6 +115,10 @@ int rpt_timing_end(rpt_ctx *ctx, float *total_ms, int *frames);
  * planes + r*plane_stride_bytes) into the 16 B/pixel framebuffer `out16` (x, y, packed colour). */
 int rpt_scatter_colour_plane(rpt_ctx *ctx, const void *planes, void *out16, int width, int height,
                              int n_ranks, int plane_stride_words, int reserved);
+/* The same on an explicit HIP stream (NULL = the context's launch stream): lets the root overlap the
+ * reassembly of frame k with the rendering of frame k+1. */
+int rpt_scatter_colour_plane_on(rpt_ctx *ctx, void *hip_stream, const void *planes, void *out16, int width, int height,
+                                int n_ranks, int plane_stride_words);
 
 /* Diagnostic variant 7 only: loop-iteration counters of the octree walk of the last frame —
  * [0..2] leaf steps / triangle tests / descent steps summed over lanes, [3..5] the same counted

@@ -797,15 +797,23 @@ int rpt_timed_frames(rpt_ctx *ctx, int frames, float *avg_ms) {
     return RPT_OK;
 }
 
+int rpt_scatter_colour_plane_on(rpt_ctx *ctx, void *hip_stream, const void *planes, void *out16, int width, int height,
+                                int n_ranks, int plane_stride_words);
+
 int rpt_scatter_colour_plane(rpt_ctx *ctx, const void *planes, void *out16, int width, int height, int n_ranks,
                              int plane_stride_words, int reserved) {
+    return rpt_scatter_colour_plane_on(ctx, ctx ? (void *)ctx->stream : nullptr, planes, out16, width, height, n_ranks, plane_stride_words);
+}
+
+int rpt_scatter_colour_plane_on(rpt_ctx *ctx, void *hip_stream, const void *planes, void *out16, int width, int height,
+                                int n_ranks, int plane_stride_words) {
     if (!ctx || !planes || !out16 || width <= 0 || height <= 0 || n_ranks <= 0 || plane_stride_words < 0) return RPT_ERR_ARG;
     const int tiles = (height + RPT_TILE_ROWS - 1) / RPT_TILE_ROWS;
     const long long need = (long long)((tiles + n_ranks - 1) / n_ranks) * RPT_TILE_ROWS * width;
     if ((long long)plane_stride_words < need) return fail(ctx, RPT_ERR_ARG, "rpt_scatter_colour_plane: plane stride smaller than one rank's plane");
     RPT_HIP(ctx, hipSetDevice(ctx->device));
     const dim3 grid((width + 255) / 256, height);
-    hipLaunchKernelGGL(rptd::rpt_scatter_plane_kernel, grid, dim3(256), 0, ctx->stream, (const uint32_t *)planes,
+    hipLaunchKernelGGL(rptd::rpt_scatter_plane_kernel, grid, dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : ctx->stream, (const uint32_t *)planes,
                        (rpt_pixel *)out16, width, height, n_ranks, (size_t)plane_stride_words);
     RPT_HIP(ctx, hipGetLastError());
     return RPT_OK;

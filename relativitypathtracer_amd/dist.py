@@ -72,36 +72,70 @@ def reassemble_planes(planes: np.ndarray, width: int, height: int, world: int) -
 
 
 class FrameSharder:
-    """Owns the output tensors of one rank and runs render (+ gather + scatter) for one frame."""
+    """Owns the output tensors of one rank and runs render (+ gather + scatter) frame after frame.
 
-    def __init__(self, renderer, width: int, height: int, rank: int, world: int, force_gather: bool = False):
+    With more than one rank the three stages of a frame run on different queues — render on the launch
+    stream, the gather on RCCL's stream, the root's reassembly on a side stream — and consecutive frames
+    overlap two deep (double-buffered planes): frame k+1 renders while frame k's plane is on the wire.
+    Per frame every rank still issues exactly one collective, in the same order on all ranks; the host
+    never blocks (buffer reuse is ordered by stream-level waits only).
+    """
+
+    def __init__(self, renderer, width: int, height: int, rank: int, world: int, force_gather: bool = False,
+                 pipeline: bool = True):
         import torch
         self.r, self.W, self.H, self.rank, self.world = renderer, width, height, rank, world
         dev = torch.device("cuda", torch.cuda.current_device())
         self.framebuffer: Optional["torch.Tensor"] = None
         self.local_rows = local_tile_count(height, rank, world) * TILE_ROWS
         self.exchange = world > 1 or force_gather      # force_gather: run the plane/gather/scatter path with one rank
+        self.depth = 2 if pipeline else 1
+        self.frame = 0
         if not self.exchange:
             renderer.set_rows(0, 1, False)
             self.framebuffer = torch.zeros(width * height * 4, dtype=torch.int32, device=dev)
             renderer.set_output(self.framebuffer.data_ptr())
-            self.plane = self.gathered = None
-        else:
-            words = plane_words(width, height, world)
-            renderer.set_rows(rank, world, True)
-            self.plane = torch.zeros(words, dtype=torch.int32, device=dev)
-            renderer.set_plane_output(self.plane.data_ptr())
-            if rank == 0:
-                self.gathered = torch.zeros((world, words), dtype=torch.int32, device=dev)
-                self.framebuffer = torch.zeros(width * height * 4, dtype=torch.int32, device=dev)
-            else:
-                self.gathered = None
+            return
+        words = plane_words(width, height, world)
+        renderer.set_rows(rank, world, True)
+        self.planes = [torch.zeros(words, dtype=torch.int32, device=dev) for _ in range(self.depth)]
+        self.works = [None] * self.depth            # gather of the frame that last used plane slot i
+        if rank == 0:
+            self.gathered = [torch.zeros((world, words), dtype=torch.int32, device=dev) for _ in range(self.depth)]
+            self.framebuffer = torch.zeros(width * height * 4, dtype=torch.int32, device=dev)
+            self.side = torch.cuda.Stream(device=dev) if pipeline else None
+            self.scattered = [None] * self.depth    # event: reassembly of the frame that last used gathered slot i
 
     def render_and_gather(self):
+        if not self.exchange:
+            self.r.render_async()
+            return
+        import torch
+        import torch.distributed as td
+        slot = self.frame % self.depth
+        self.frame += 1
+        cur = torch.cuda.current_stream()
+        if self.works[slot] is not None:
+            self.works[slot].wait()                 # stream-level: this plane slot has left the GPU
+        if self.rank == 0 and self.scattered[slot] is not None:
+            cur.wait_event(self.scattered[slot])    # this gather slot has been consumed by the reassembly
+        self.r.set_plane_output(self.planes[slot].data_ptr())
         self.r.render_async()
-        if self.exchange:
-            import torch.distributed as td
-            td.gather(self.plane, list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0)
-            if self.rank == 0:
-                self.r.scatter_colour_plane(self.gathered.data_ptr(), self.framebuffer.data_ptr(), self.W, self.H,
-                                            self.world, self.gathered.shape[1])
+        glist = list(self.gathered[slot].unbind(0)) if self.rank == 0 else None
+        work = td.gather(self.planes[slot], glist, dst=0, async_op=True)      # the one exchange step of the frame
+        self.works[slot] = work
+        if self.rank == 0:
+            if self.side is None:
+                work.wait()
+                self.r.scatter_colour_plane(self.gathered[slot].data_ptr(), self.framebuffer.data_ptr(), self.W, self.H,
+                                            self.world, self.gathered[slot].shape[1])
+            else:
+                with torch.cuda.stream(self.side):
+                    work.wait()
+                    self.r.scatter_colour_plane(self.gathered[slot].data_ptr(), self.framebuffer.data_ptr(), self.W, self.H,
+                                                self.world, self.gathered[slot].shape[1], stream=self.side.cuda_stream)
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)
+                    self.scattered[slot] = ev
+        elif self.depth == 1:
+            work.wait()

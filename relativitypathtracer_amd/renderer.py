@@ -141,9 +141,9 @@ class Renderer:
         return ms.value
 
     def scatter_colour_plane(self, planes_ptr: int, out16_ptr: int, width: int, height: int, n_ranks: int,
-                             plane_stride_words: int):
-        self._check(self._lib.rpt_scatter_colour_plane(self._h, C.c_void_p(planes_ptr), C.c_void_p(out16_ptr), width,
-                                                       height, n_ranks, plane_stride_words, 0),
+                             plane_stride_words: int, stream: Optional[int] = None):
+        self._check(self._lib.rpt_scatter_colour_plane_on(self._h, C.c_void_p(stream or 0), C.c_void_p(planes_ptr),
+                                                          C.c_void_p(out16_ptr), width, height, n_ranks, plane_stride_words),
                     "rpt_scatter_colour_plane")
 
     def read_counters(self):
