@@ -228,3 +228,24 @@ def test_non_consecutive_children_fall_back_to_general_kernel(renderer):
     got = renderer.read_framebuffer()
     opx, _, _ = oracle_ffi.render(scene, W, H, want_rgb=False)
     assert np.array_equal(got["rgba"], opx["rgba"])
+
+
+def test_dense_synthetic_mesh_matches_oracle(renderer, tmp_path):
+    """NON-REFERENCE data: bunny.obj subdivided 1->4 twice (79 488 triangles, 38 k nodes, leaves
+    with many triangles) in the bunny scene — a larger octree than anything the reference ships."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from dense_mesh import dense_bunny_scene
+    scene = dense_bunny_scene(str(tmp_path), 2)
+    assert scene.desc().triangle_words == 9 * 79488
+    scene.set_camera((0, 0, 0), 0.0)
+    scene.update_objects()
+    W, H = 640, 360
+    for variant in (0, 1):
+        _setup(renderer, scene, W, H, variant)
+        renderer.set_debug_rgb(True)
+        renderer.render()
+        px, rgb = renderer.read_framebuffer(), renderer.read_debug_rgb()
+        opx, orgb, _ = oracle_ffi.render(scene, W, H)
+        assert np.array_equal(px["rgba"], opx["rgba"])
+        assert np.array_equal(rgb.view(np.uint32), orgb.view(np.uint32))
