@@ -131,6 +131,17 @@ int rpt_read_counters(rpt_ctx *ctx, unsigned long long out[16]);
  * frame, wave w = (blockIdx.y*gridDim.x + blockIdx.x)*4 + wave-in-block. */
 int rpt_read_wave_times(rpt_ctx *ctx, unsigned long long *out, size_t max_words, size_t *words);
 
+/* GPU octree build (replaces Mesh::GenerateOctree, Mesh.cpp:5-28, and Subdivide, Octree.cpp:171-248): builds the
+ * octree of the mesh whose triangles start at word `first_triangle_word` of `triangles` (the root lists every
+ * triangle imported so far, as the reference's does).  The triangle/box classification runs on the device;
+ * the result — node order, lists, neighbour links — is byte-identical to the host builder's.  Node and list
+ * indices in the output are absolute, based at node_index_base / tri_index_base (the current lengths of the
+ * host's octree and octreeTris arrays).  The two arrays are malloc()ed; release them with rpt_free_host. */
+int rpt_build_octree(rpt_ctx *ctx, const rpt_float3 *vertices, size_t vertex_count, const uint32_t *triangles,
+                     size_t triangle_words, size_t first_triangle_word, int node_index_base, int tri_index_base,
+                     rpt_octree **nodes_out, size_t *node_count, int32_t **tris_out, size_t *tri_count);
+void rpt_free_host(void *p);
+
 /* Known-answer probes of individual device functions (tests): which = 0 intersect_triangle
  * (in 15 floats -> out 4), 1 intersect_AABB (12 -> 5), 2 createCamRay (4 -> 3), 3 hable (3 -> 3). */
 int rpt_probe(rpt_ctx *ctx, int which, const void *host_in, void *host_out, int n);

@@ -49,6 +49,11 @@ int rpt_scene_set_texture_decoder(rpt_scene *s, rpt_texture_decoder fn, void *us
 /* scene construction */
 int rpt_scene_input(rpt_scene *s, const char *text);                 /* the whole DSL text, as piped to stdin */
 int rpt_scene_read_obj(rpt_scene *s, const char *path);
+/* ReadOBJ() in two steps, for an octree built elsewhere (rpt_build_octree on the GPU, include/rpt.h): import the
+ * geometry (vertices, 9-word triangles, synthesised normals; Render.cpp:436-533), then append the finished
+ * octree (what Mesh::GenerateOctree would have produced; indices absolute). */
+int rpt_scene_read_obj_geometry(rpt_scene *s, const char *path, size_t *first_triangle_word);
+int rpt_scene_append_octree(rpt_scene *s, const rpt_octree *nodes, size_t node_count, const int32_t *tris, size_t tri_count);
 int rpt_scene_read_texture(rpt_scene *s, const char *path);
 int rpt_scene_add_texture_rgb8(rpt_scene *s, const unsigned char *rgb, int width, int height);
 

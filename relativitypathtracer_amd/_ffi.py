@@ -89,6 +89,8 @@ def scene_lib() -> C.CDLL:
             "rpt_scene_set_texture_decoder": (I, [P, TextureDecoder, P]),
             "rpt_scene_input": (I, [P, S]),
             "rpt_scene_read_obj": (I, [P, S]),
+            "rpt_scene_read_obj_geometry": (I, [P, S, C.POINTER(C.c_size_t)]),
+            "rpt_scene_append_octree": (I, [P, P, C.c_size_t, P, C.c_size_t]),
             "rpt_scene_read_texture": (I, [P, S]),
             "rpt_scene_add_texture_rgb8": (I, [P, P, I, I]),
             "rpt_scene_set_camera": (I, [P, FP, FP]),
@@ -143,6 +145,9 @@ HIP_SYMBOLS = {
     "rpt_timing_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "rpt_read_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rpt_read_wave_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "rpt_build_octree": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
+                                   C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "rpt_free_host": (None, [C.c_void_p]),
     "rpt_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "rpt_version": (C.c_char_p, []),
 }

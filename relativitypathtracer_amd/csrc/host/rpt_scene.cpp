@@ -128,6 +128,25 @@ bool Scene::ReadTexture(const std::string &path) {
 
 // Render.cpp:436-538
 bool Scene::ReadOBJ(const std::string &path) {
+    int firstTriIndex = 0;
+    if (!ReadOBJGeometry(path, firstTriIndex)) return false;
+    theMesh.meshIndices.push_back((int)theMesh.octree.size());
+    theMesh.GenerateOctree(firstTriIndex);
+    return true;
+}
+
+// An octree built elsewhere (rpt_build_octree on the GPU) for the geometry ReadOBJGeometry just appended:
+// node and triangle indices are already absolute (based at the current array sizes).
+bool Scene::AppendOctree(const rpt_octree *nodes, size_t node_count, const int32_t *tris, size_t tri_count) {
+    if (!nodes || !node_count || (!tris && tri_count)) { lastError = "AppendOctree: empty octree"; return false; }
+    theMesh.meshIndices.push_back((int)theMesh.octree.size());
+    theMesh.octree.insert(theMesh.octree.end(), nodes, nodes + node_count);
+    theMesh.octreeTris.insert(theMesh.octreeTris.end(), tris, tris + tri_count);
+    return true;
+}
+
+// Render.cpp:436-533: everything ReadOBJ does before GenerateOctree
+bool Scene::ReadOBJGeometry(const std::string &path, int &firstTriIndexOut) {
     Mesh &mesh = theMesh;
     if (path.size() < 4 || path.substr(path.size() - 4, 4) != ".obj") { lastError = "ReadOBJ: not an .obj file: " + path; return false; }
     std::ifstream file(resolve(path));
@@ -210,8 +229,7 @@ bool Scene::ReadOBJ(const std::string &path) {
         }
         mesh.normals.push_back(normalize(N));
     }
-    mesh.meshIndices.push_back((int)mesh.octree.size());
-    mesh.GenerateOctree(firstTriIndex);
+    firstTriIndexOut = firstTriIndex;
     return true;
 }
 

@@ -63,6 +63,8 @@ struct Scene {
     bool ReadTexture(const std::string &path);         // Render.cpp:418-434
     bool AddTexture(const uint8_t *rgb, int width, int height);
     bool ReadOBJ(const std::string &path);             // Render.cpp:436-538
+    bool ReadOBJGeometry(const std::string &path, int &firstTriIndex);   // the same without Mesh::GenerateOctree
+    bool AppendOctree(const rpt_octree *nodes, size_t node_count, const int32_t *tris, size_t tri_count);
     bool finalizeIndices();                            // Render.cpp:393-413
     void updateObjects();                              // Render.cpp:179-200 (per-frame Lorentz refresh)
     void accelerate(rpt_float3 direction, int frame_ms);   // Render.cpp:159-176 (WASDQE)

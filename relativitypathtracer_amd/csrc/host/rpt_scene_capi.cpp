@@ -75,6 +75,22 @@ int rpt_scene_read_obj(rpt_scene *s, const char *path) {
     RPT_END(s)
 }
 
+int rpt_scene_read_obj_geometry(rpt_scene *s, const char *path, size_t *first_triangle_word) {
+    RPT_GUARD(s)
+    if (!path || !first_triangle_word) return -1;
+    int first = 0;
+    if (!s->scene.ReadOBJGeometry(path, first)) return 1;
+    *first_triangle_word = (size_t)first;
+    return 0;
+    RPT_END(s)
+}
+
+int rpt_scene_append_octree(rpt_scene *s, const rpt_octree *nodes, size_t node_count, const int32_t *tris, size_t tri_count) {
+    RPT_GUARD(s)
+    return s->scene.AppendOctree(nodes, node_count, tris, tri_count) ? 0 : 1;
+    RPT_END(s)
+}
+
 int rpt_scene_read_texture(rpt_scene *s, const char *path) {
     RPT_GUARD(s)
     if (!path) return -1;

@@ -8,12 +8,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <functional>
 #include <string>
 #include <utility>
 #include <vector>
 
 #include "../../include/rpt.h"
 #include "rpt_kernels.hip.h"
+#include "rpt_octree_build.hip.h"
 
 #pragma clang fp contract(off)
 
@@ -864,3 +866,229 @@ int rpt_probe(rpt_ctx *ctx, int which, const void *host_in, void *host_out, int 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// GPU octree build: replaces Mesh::GenerateOctree (Mesh.cpp:5-28) + Subdivide
+// (Octree.cpp:171-248).  The triangle/box classification of each level runs on the device
+// (rpt_octree_build.hip.h); the O(nodes) bookkeeping — child boxes, the valence stop rule, the reference's
+// depth-first numbering of nodes and lists, neighbour links — is done here with the host builder's
+// arithmetic, so the output is byte-identical to csrc/host/rpt_octree.cpp.
+namespace {
+
+struct BuildNode {
+    float mn[3], mx[3];
+    unsigned int list_begin = 0, list_count = 0;   // in its level's list buffer
+    int min_tris = 0, depth = 0;
+    int first_child = -1;                           // index in the next level's node array, -1 = not split
+    int valence = 0;
+};
+
+struct DevTemp {
+    void *p = nullptr;
+    ~DevTemp() { if (p) (void)hipFree(p); }
+};
+
+}  // namespace
+
+extern "C" void rpt_free_host(void *p) { std::free(p); }
+
+extern "C" int rpt_build_octree(rpt_ctx *ctx, const rpt_float3 *vertices, size_t vertex_count, const uint32_t *triangles,
+                                size_t triangle_words, size_t first_triangle_word, int node_index_base, int tri_index_base,
+                                rpt_octree **nodes_out, size_t *node_count, int32_t **tris_out, size_t *tri_count) {
+    if (!ctx || !vertices || !triangles || !nodes_out || !node_count || !tris_out || !tri_count) return RPT_ERR_ARG;
+    if (triangle_words % 9 || first_triangle_word % 9 || first_triangle_word >= triangle_words)
+        return fail(ctx, RPT_ERR_ARG, "rpt_build_octree: triangle words must be a multiple of 9 and the mesh must have triangles");
+    const size_t n_tris_total = triangle_words / 9;
+    if (n_tris_total > (size_t)0x3fffffff) return fail(ctx, RPT_ERR_ARG, "rpt_build_octree: too many triangles");
+    for (size_t w = 0; w < triangle_words; w += 3)
+        if (triangles[w] >= vertex_count) return fail(ctx, RPT_ERR_SCENE, "rpt_build_octree: vertex index out of range");
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+
+    // root (Mesh.cpp:6-21): bounds over this mesh's face-corner vertices, list = every triangle imported so far
+    std::vector<std::vector<BuildNode>> levels(1);
+    std::vector<std::vector<int32_t>> lists(1);       // host copies of every level's concatenated lists
+    {
+        BuildNode root;
+        const rpt_float3 v0 = vertices[triangles[first_triangle_word]];
+        root.mn[0] = root.mx[0] = v0.x; root.mn[1] = root.mx[1] = v0.y; root.mn[2] = root.mx[2] = v0.z;
+        for (size_t i = first_triangle_word / 3; i < triangle_words / 3; i++) {
+            const rpt_float3 v = vertices[triangles[3 * i]];
+            const float c[3] = {v.x, v.y, v.z};
+            for (int k = 0; k < 3; k++) {
+                root.mn[k] = root.mn[k] < c[k] ? root.mn[k] : c[k];
+                root.mx[k] = root.mx[k] > c[k] ? root.mx[k] : c[k];
+            }
+        }
+        root.list_begin = 0;
+        root.list_count = (unsigned int)n_tris_total;
+        root.min_tris = 0;
+        root.depth = 6;
+        levels[0].push_back(root);
+        lists[0].resize(n_tris_total);
+        for (size_t t = 0; t < n_tris_total; t++) lists[0][t] = (int32_t)t;
+    }
+
+    DevTemp d_vertices, d_triangles;
+    RPT_HIP(ctx, hipMalloc(&d_vertices.p, vertex_count * sizeof(rpt_float3)));
+    RPT_HIP(ctx, hipMalloc(&d_triangles.p, triangle_words * sizeof(uint32_t)));
+    RPT_HIP(ctx, hipMemcpy(d_vertices.p, vertices, vertex_count * sizeof(rpt_float3), hipMemcpyHostToDevice));
+    RPT_HIP(ctx, hipMemcpy(d_triangles.p, triangles, triangle_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+
+    std::vector<int> vertex_hits(vertex_count, 0);
+    for (size_t l = 0; l < levels.size(); l++) {
+        std::vector<BuildNode> &nodes = levels[l];
+        const std::vector<int32_t> &list = lists[l];
+        std::vector<rptb::ChildDesc> children;
+        std::vector<unsigned int> chunk_child;
+        unsigned int flag_total = 0;
+        for (BuildNode &n : nodes) {
+            if (n.depth <= 0 || (int)n.list_count <= n.min_tris) continue;      // Octree.cpp:172
+            // stop rule for the children: most triangles of this node around one vertex (Octree.cpp:180-190)
+            int valence = 0;
+            for (unsigned int i = 0; i < n.list_count; i++)
+                for (int k = 0; k < 3; k++) {
+                    const int c = ++vertex_hits[triangles[9 * list[n.list_begin + i] + 3 * k]];
+                    valence = c > valence ? c : valence;
+                }
+            for (unsigned int i = 0; i < n.list_count; i++)
+                for (int k = 0; k < 3; k++) vertex_hits[triangles[9 * list[n.list_begin + i] + 3 * k]] = 0;
+            n.valence = valence;
+            n.first_child = (int)children.size();
+            const float hx = (n.mx[0] - n.mn[0]) / 2, hy = (n.mx[1] - n.mn[1]) / 2, hz = (n.mx[2] - n.mn[2]) / 2;
+            for (int x = 0; x < 2; x++)
+                for (int y = 0; y < 2; y++)
+                    for (int z = 0; z < 2; z++) {       // creation order == child index z + 2y + 4x (Octree.cpp:191-201)
+                        rptb::ChildDesc c;
+                        // child.min = min + ex*x + ey*y + ez*z, component by component, zeros included
+                        c.minx = n.mn[0] + hx * (float)x + 0.0f * (float)y + 0.0f * (float)z;
+                        c.miny = n.mn[1] + 0.0f * (float)x + hy * (float)y + 0.0f * (float)z;
+                        c.minz = n.mn[2] + 0.0f * (float)x + 0.0f * (float)y + hz * (float)z;
+                        c.maxx = c.minx + hx; c.maxy = c.miny + hy; c.maxz = c.minz + hz;
+                        c.list_begin = n.list_begin;
+                        c.list_count = n.list_count;
+                        c.flag_base = flag_total;
+                        c.chunk_base = (unsigned int)chunk_child.size();
+                        flag_total += n.list_count;
+                        for (unsigned int k = 0; k < (n.list_count + 255) / 256; k++) chunk_child.push_back((unsigned int)children.size());
+                        children.push_back(c);
+                    }
+        }
+        if (children.empty()) break;
+
+        // device: classify (child, parent entry), count per chunk, compact in order
+        const unsigned int n_chunks = (unsigned int)chunk_child.size();
+        DevTemp d_list, d_children, d_chunk_child, d_flags, d_counts, d_chunk_out, d_next;
+        RPT_HIP(ctx, hipMalloc(&d_list.p, list.size() * sizeof(int32_t)));
+        RPT_HIP(ctx, hipMalloc(&d_children.p, children.size() * sizeof(rptb::ChildDesc)));
+        RPT_HIP(ctx, hipMalloc(&d_chunk_child.p, n_chunks * sizeof(unsigned int)));
+        RPT_HIP(ctx, hipMalloc(&d_flags.p, (size_t)flag_total + 16));
+        RPT_HIP(ctx, hipMalloc(&d_counts.p, n_chunks * sizeof(unsigned int)));
+        RPT_HIP(ctx, hipMalloc(&d_chunk_out.p, n_chunks * sizeof(unsigned int)));
+        RPT_HIP(ctx, hipMemcpy(d_list.p, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        RPT_HIP(ctx, hipMemcpy(d_children.p, children.data(), children.size() * sizeof(rptb::ChildDesc), hipMemcpyHostToDevice));
+        RPT_HIP(ctx, hipMemcpy(d_chunk_child.p, chunk_child.data(), n_chunks * sizeof(unsigned int), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(rptb::sat_flag_kernel, dim3(n_chunks), dim3(256), 0, ctx->stream, (const rpt_float3 *)d_vertices.p,
+                           (const uint32_t *)d_triangles.p, (const int32_t *)d_list.p, (const rptb::ChildDesc *)d_children.p,
+                           (const unsigned int *)d_chunk_child.p, (unsigned char *)d_flags.p, (unsigned int *)d_counts.p, n_chunks);
+        RPT_HIP(ctx, hipGetLastError());
+        std::vector<unsigned int> counts(n_chunks), chunk_out(n_chunks);
+        RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        RPT_HIP(ctx, hipMemcpy(counts.data(), d_counts.p, n_chunks * sizeof(unsigned int), hipMemcpyDeviceToHost));
+        unsigned long long total = 0;
+        for (unsigned int k = 0; k < n_chunks; k++) {
+            chunk_out[k] = (unsigned int)total;
+            total += counts[k];
+        }
+        if (total > 0x7fffffffull) return fail(ctx, RPT_ERR_NOMEM, "rpt_build_octree: triangle lists exceed 2^31 entries");
+        std::vector<int32_t> next_list((size_t)total);
+        if (total) {
+            RPT_HIP(ctx, hipMalloc(&d_next.p, (size_t)total * sizeof(int32_t)));
+            RPT_HIP(ctx, hipMemcpy(d_chunk_out.p, chunk_out.data(), n_chunks * sizeof(unsigned int), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(rptb::sat_compact_kernel, dim3(n_chunks), dim3(256), 0, ctx->stream, (const int32_t *)d_list.p,
+                               (const rptb::ChildDesc *)d_children.p, (const unsigned int *)d_chunk_child.p,
+                               (const unsigned char *)d_flags.p, (const unsigned int *)d_chunk_out.p, (int32_t *)d_next.p, n_chunks);
+            RPT_HIP(ctx, hipGetLastError());
+            RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            RPT_HIP(ctx, hipMemcpy(next_list.data(), d_next.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost));
+        }
+        // next level's nodes: the children, their lists consecutive in child order
+        std::vector<BuildNode> next_nodes(children.size());
+        size_t parent_of_child = 0;
+        std::vector<int> parent_index(children.size());
+        for (size_t pi = 0; pi < nodes.size(); pi++)
+            if (nodes[pi].first_child >= 0)
+                for (int k = 0; k < 8; k++) parent_index[(size_t)nodes[pi].first_child + k] = (int)pi;
+        (void)parent_of_child;
+        for (size_t c = 0; c < children.size(); c++) {
+            BuildNode &b = next_nodes[c];
+            b.mn[0] = children[c].minx; b.mn[1] = children[c].miny; b.mn[2] = children[c].minz;
+            b.mx[0] = children[c].maxx; b.mx[1] = children[c].maxy; b.mx[2] = children[c].maxz;
+            const unsigned int k0 = children[c].chunk_base, k1 = c + 1 < children.size() ? children[c + 1].chunk_base : n_chunks;
+            b.list_begin = chunk_out[k0];
+            unsigned int cnt = 0;
+            for (unsigned int k = k0; k < k1; k++) cnt += counts[k];
+            b.list_count = cnt;
+            b.min_tris = nodes[parent_index[c]].valence;
+            b.depth = nodes[parent_index[c]].depth - 1;
+        }
+        levels.push_back(std::move(next_nodes));
+        lists.push_back(std::move(next_list));
+    }
+
+    // the reference's numbering: a node's eight children and their lists are appended when the node is split,
+    // and the children are then visited depth first (Octree.cpp:191-246)
+    std::vector<rpt_octree> out_nodes;
+    std::vector<int32_t> out_tris;
+    auto make_node = [&](const BuildNode &b, const std::vector<int32_t> &list) {
+        rpt_octree o;
+        std::memset(&o, 0, sizeof o);
+        o.min.x = b.mn[0]; o.min.y = b.mn[1]; o.min.z = b.mn[2];
+        o.max.x = b.mx[0]; o.max.y = b.mx[1]; o.max.z = b.mx[2];
+        o.trisIndex = tri_index_base + (int)out_tris.size();
+        o.trisCount = (int)b.list_count;
+        for (int &c : o.children) c = -1;
+        for (int &n : o.neighbors) n = -1;
+        out_tris.insert(out_tris.end(), list.begin() + b.list_begin, list.begin() + b.list_begin + b.list_count);
+        out_nodes.push_back(o);
+    };
+    make_node(levels[0][0], lists[0]);
+    struct Frame { size_t level; int index; int out; };
+    // explicit recursion: emit(level, index in level, output index)
+    std::function<void(size_t, int, int)> emit = [&](size_t level, int index, int out) {
+        const BuildNode &b = levels[level][index];
+        if (b.first_child < 0) return;
+        int child_out[8];
+        for (int k = 0; k < 8; k++) {
+            child_out[k] = (int)out_nodes.size();
+            out_nodes[out].children[k] = node_index_base + child_out[k];
+            make_node(levels[level + 1][b.first_child + k], lists[level + 1]);
+        }
+        const rpt_octree parent = out_nodes[out];
+        for (int k = 0; k < 8; k++) {        // neighbour links (Octree.cpp:213-244): -z,+z,-x,+x,-y,+y
+            const int bit[3] = {k & 1, (k >> 2) & 1, (k >> 1) & 1}, step[3] = {1, 4, 2};
+            rpt_octree &c = out_nodes[child_out[k]];
+            for (int axis = 0; axis < 3; axis++) {
+                const int lo = 2 * axis, hi = 2 * axis + 1;
+                if (bit[axis] == 0) { c.neighbors[lo] = parent.neighbors[lo]; c.neighbors[hi] = parent.children[k + step[axis]]; }
+                else { c.neighbors[lo] = parent.children[k - step[axis]]; c.neighbors[hi] = parent.neighbors[hi]; }
+            }
+        }
+        for (int k = 0; k < 8; k++) emit(level + 1, b.first_child + k, child_out[k]);
+    };
+    emit(0, 0, 0);
+
+    rpt_octree *nodes_host = (rpt_octree *)std::malloc(out_nodes.size() * sizeof(rpt_octree));
+    int32_t *tris_host = (int32_t *)std::malloc((out_tris.size() ? out_tris.size() : 1) * sizeof(int32_t));
+    if (!nodes_host || !tris_host) {
+        std::free(nodes_host);
+        std::free(tris_host);
+        return fail(ctx, RPT_ERR_NOMEM, "rpt_build_octree: out of host memory");
+    }
+    std::memcpy(nodes_host, out_nodes.data(), out_nodes.size() * sizeof(rpt_octree));
+    if (!out_tris.empty()) std::memcpy(tris_host, out_tris.data(), out_tris.size() * sizeof(int32_t));
+    *nodes_out = nodes_host;
+    *node_count = out_nodes.size();
+    *tris_out = tris_host;
+    *tri_count = out_tris.size();
+    return RPT_OK;
+}

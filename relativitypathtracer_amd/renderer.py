@@ -158,6 +158,21 @@ class Renderer:
         self._check(self._lib.rpt_read_wave_times(self._h, out.ctypes.data, n, C.byref(got)), "rpt_read_wave_times")
         return out[:got.value].reshape(-1, 10)
 
+    def build_octree(self, scene: Scene, first_triangle_word: int):
+        """GPU octree build for the geometry `scene.ReadOBJ(..., octree=False)` just imported; appends it to the scene."""
+        d = scene.desc()
+        nodes, tris = C.c_void_p(), C.c_void_p()
+        n_nodes, n_tris = C.c_size_t(), C.c_size_t()
+        self._check(self._lib.rpt_build_octree(self._h, d.vertices, d.vertex_count, d.triangles, d.triangle_words,
+                                               first_triangle_word, d.octree_count, d.octree_tri_count,
+                                               C.byref(nodes), C.byref(n_nodes), C.byref(tris), C.byref(n_tris)),
+                    "rpt_build_octree")
+        try:
+            scene.append_octree(nodes.value, n_nodes.value, tris.value, n_tris.value)
+        finally:
+            self._lib.rpt_free_host(nodes)
+            self._lib.rpt_free_host(tris)
+
     def probe(self, which: int, inputs: np.ndarray, out_width: int) -> np.ndarray:
         inputs = np.ascontiguousarray(inputs, dtype=np.float32)
         n = inputs.shape[0]

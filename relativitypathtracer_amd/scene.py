@@ -82,8 +82,19 @@ class Scene:
         self._check(self._lib.rpt_scene_input(self._h, text.encode()), "inputScene")
         return self._lib.rpt_scene_last_error(self._h).decode()
 
-    def ReadOBJ(self, path: str):
-        self._check(self._lib.rpt_scene_read_obj(self._h, path.encode()), "ReadOBJ")
+    def ReadOBJ(self, path: str, octree: bool = True) -> int:
+        """Import an OBJ.  octree=False imports the geometry only and returns the word offset of its first triangle,
+        for Renderer.build_octree (the GPU builder) to finish."""
+        if octree:
+            self._check(self._lib.rpt_scene_read_obj(self._h, path.encode()), "ReadOBJ")
+            return -1
+        first = C.c_size_t()
+        self._check(self._lib.rpt_scene_read_obj_geometry(self._h, path.encode(), C.byref(first)), "ReadOBJ")
+        return first.value
+
+    def append_octree(self, nodes_ptr: int, node_count: int, tris_ptr: int, tri_count: int):
+        self._check(self._lib.rpt_scene_append_octree(self._h, C.c_void_p(nodes_ptr), node_count, C.c_void_p(tris_ptr), tri_count),
+                    "append_octree")
 
     def ReadTexture(self, path: str):
         self._check(self._lib.rpt_scene_read_texture(self._h, path.encode()), "ReadTexture")
