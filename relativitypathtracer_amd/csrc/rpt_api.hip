@@ -396,16 +396,9 @@ int launch(rpt_ctx *ctx) {
         row_cost_dev = (unsigned int *)ctx->row_cost.ptr + (size_t)tiles * (ctx->row_parity & 1);
         a.row_cost = row_cost_dev;
     }
-    // variant 0 = default: the derived-layout kernel when the octree allows it, else the general one; with
-    // several objects the tile-binned form (per-tile object masks) wins by a large factor, with two or three
-    // the plain per-pixel loop is as fast (measured: DESIGN.md §6)
-    int v = ctx->variant;
-    if (v == 0) {
-        bool has_mesh = false;
-        for (int i = 0; i < ctx->object_count; i++)
-            if (((const rpt_object *)ctx->host_objects.data())[i].type == RPT_MESH) has_mesh = true;
-        v = (ctx->object_count >= 8 || (ctx->object_count >= 4 && !has_mesh)) ? 13 : 3;
-    }
+    // variant 0 = default: the derived-layout per-pixel kernel in natural dispatch order with the per-tile object
+    // masks of the prepass (25) when the octree allows the derived layout, else the general kernel (1)
+    int v = ctx->variant == 0 ? 25 : ctx->variant;
     if (!ctx->compact_ok) v = 1;
     switch (v) {
     case 1: hipLaunchKernelGGL(rptd::rpt_render_kernel_v0, grid, dim3(256), 0, ctx->stream, a); break;
@@ -476,6 +469,20 @@ int launch(rpt_ctx *ctx) {
     case 19: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_packet_w4, grid, dim3(256), 0, ctx->stream, a); break;
     case 20: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_half, dim3(grid.x, grid.y * 2), dim3(256), 0, ctx->stream, a); break;
     case 21: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_quarter, dim3((ctx->width + 15) / 16, grid.y * 2), dim3(256), 0, ctx->stream, a); break;
+    case 25: {   // natural order, per-tile object masks from the prepass (no lists)
+        const int tiles_x = ((ctx->width + 31) / 32) * 4;          // tiles per row as the 32-pixel-wide blocks see them
+        const int n_tiles = tiles_x * tiles;
+        if (int rc = reserve(ctx, ctx->tile_masks, (size_t)n_tiles * 8)) return rc;
+        a.tiles_x = tiles_x;
+        a.n_tiles = n_tiles;
+        a.tile_masks = (unsigned long long *)ctx->tile_masks.ptr;
+        a.bin_lists = nullptr;
+        a.bin_counts = nullptr;
+        a.mesh_object_bits = 0;
+        hipLaunchKernelGGL(rptd::rpt_tile_bin_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked, grid, dim3(256), 0, ctx->stream, a);
+        break;
+    }
     case 14: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_prio, grid, dim3(256), 0, ctx->stream, a); break;
     case 8: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only, grid, dim3(256), 0, ctx->stream, a); break;
     case 9: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only_w6, grid, dim3(256), 0, ctx->stream, a); break;
@@ -667,7 +674,7 @@ int rpt_set_debug_rgb(rpt_ctx *ctx, void *p) {
 }
 
 int rpt_set_variant(rpt_ctx *ctx, int variant) {
-    if (!ctx || variant < 0 || variant > 21) return RPT_ERR_ARG;
+    if (!ctx || variant < 0 || variant > 25) return RPT_ERR_ARG;
     ctx->variant = variant;
     return RPT_OK;
 }

@@ -1053,11 +1053,18 @@ RPT_DEV void render_pixel_body(const KernelArgs &a, const RowOrder *order = null
     const int y_coord = (a.first_tile + tile_row * a.tile_step) * RPT_TILE_ROWS + row_in_tile;
     if (x_coord >= a.width || y_coord >= a.height) return;   // the reference has no guard (UB)
 
-    const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);
     f3 color;
     f3 mapped = mk3(a.bg_mapped[0], a.bg_mapped[1], a.bg_mapped[2]);
     uint32_t packed = a.bg_packed;
-    if (trace<V>(a, camdir, ~0ull, color)) packed = tonemap_pack(a, color, mapped);
+    unsigned long long object_mask = ~0ull;
+    if (V == 10) {   // per-tile object mask of the binning prepass, natural dispatch order
+        const int tile = __builtin_amdgcn_readfirstlane(tile_row * a.tiles_x + (int)blockIdx.x * 4 + wave);
+        object_mask = a.tile_masks[tile];
+    }
+    if (V != 10 || object_mask != 0 || a.object_count > 64) {
+        const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);
+        if (trace<V>(a, camdir, object_mask, color)) packed = tonemap_pack(a, color, mapped);
+    }
 
     const size_t id = (size_t)y_coord * a.width + x_coord;
     if (a.out16) {
@@ -1108,6 +1115,7 @@ __global__ __launch_bounds__(256) void rpt_render_kernel_v1_packet(const KernelA
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_packet_w4(const KernelArgs a) { render_pixel_body<8>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_half(const KernelArgs a) { render_pixel_body<1, 1>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_quarter(const KernelArgs a) { render_pixel_body<1, 2>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_masked(const KernelArgs a) { render_pixel_body<10>(a); }
 __global__ __launch_bounds__(256) void rpt_render_kernel_primary_only(const KernelArgs a) { render_pixel_body<3>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_primary_only_w6(const KernelArgs a) { render_pixel_body<3>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_primary_only_w8(const KernelArgs a) { render_pixel_body<3>(a); }
@@ -1179,6 +1187,7 @@ __global__ __launch_bounds__(256) void rpt_tile_bin_kernel(const KernelArgs a) {
         if (a.object_count > 64) mask |= 0ull;   // objects >= 64 are never culled (trace() tests them always)
         a.tile_masks[tile] = mask;
     }
+    if (!a.bin_lists) return;      // masks only (the per-pixel kernel in natural order reads them)
     // class 0: a mesh may be hit (octree walk: the long waves, scheduled first); 1: analytic objects only;
     // 2: nothing (background fill).  With more than 64 objects every tile is at least class 1.
     int cls = 2;

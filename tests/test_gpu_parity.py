@@ -41,7 +41,7 @@ SIZES = {"cube": (640, 480), "arch": (480, 270), "arch_t0": (480, 270), "bunny":
 EXACT = {"cube", "arch", "arch_t0", "bunny", "shadows", "cubes", "rulers", "ladder"}
 
 
-VARIANTS = [0, 1, 2, 3, 4, 5, 6, 12, 13, 15, 16, 17, 18, 19, 20, 21]   # 0 = default; 1 = reference-layout kernel; 2..6 = derived-layout kernels; 12 = tile-binned
+VARIANTS = [0, 1, 2, 3, 4, 5, 6, 12, 13, 15, 16, 17, 18, 19, 20, 21, 25]   # 0 = default; 1 = reference-layout kernel; 2..6 = derived-layout kernels; 12 = tile-binned
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -91,10 +91,11 @@ def test_tile_culling_never_drops_a_hit(renderer):
         s.set_camera(tuple(float(c) for c in v), float(rng.uniform(-5, 25)))
         s.update_objects()
         frames = []
-        for variant in (2, 12):
+        for variant in (2, 12, 25):
             px, rgb = _render_gpu(renderer, s, W, H, variant)
             frames.append((px, rgb))
-        assert np.array_equal(frames[0][0]["rgba"], frames[1][0]["rgba"]), f"{name} {W}x{H} v={v}: packed bytes differ"
-        assert np.array_equal(frames[0][1].view(np.uint32), frames[1][1].view(np.uint32))
+        for other in frames[1:]:
+            assert np.array_equal(frames[0][0]["rgba"], other[0]["rgba"]), f"{name} {W}x{H} v={v}: packed bytes differ"
+            assert np.array_equal(frames[0][1].view(np.uint32), other[1].view(np.uint32))
         checked += int((frames[0][0]["rgba"][:, :3] != frames[0][0]["rgba"][0, :3]).any())
     assert checked > 80     # most trials actually had something on screen
