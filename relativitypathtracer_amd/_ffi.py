@@ -157,6 +157,24 @@ def hip_lib_path() -> str:
     return _path("librpt_hip.so")
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  Whichever copy is loaded
+    first serves the whole process; if ours pulls in the system copy first, a later ``import torch`` finds no
+    GPU.  So when torch is installed, load ITS runtime first (without importing torch) and let librpt_hip.so bind to it."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def hip() -> C.CDLL:
     """Load librpt_hip.so (the product render path).  Raises if it is missing — there is no fallback."""
     global _hip_lib
@@ -165,6 +183,7 @@ def hip() -> C.CDLL:
         if not os.path.exists(p):
             raise RuntimeError(f"{p} is missing: the HIP render path has no CPU fallback; build it with "
                                "`python -c 'import __graft_entry__ as g; g.build()'`")
+        _share_torch_hip_runtime()
         lib = C.CDLL(p)
         for name, (res, args) in HIP_SYMBOLS.items():
             fn = getattr(lib, name)   # AttributeError here = header/library mismatch
