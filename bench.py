@@ -133,14 +133,24 @@ def main():
     n_objects = scene.desc().object_count
 
     r = Renderer(local_rank)
-    stream = torch.cuda.current_stream()
+    # a real (non-null) stream for everything: the render kernels, torch's tensor ops and what RCCL synchronises
+    # with must be ONE stream — torch's default stream has handle 0, which the C-ABI reads as "the context's own stream"
+    stream = torch.cuda.Stream(device=torch.device("cuda", local_rank))
+    torch.cuda.set_stream(stream)
     r.set_stream(stream.cuda_stream)
     r.upload_scene(scene)
     r.set_scene_params(scene, W, H)
     r.set_variant(args.variant)
     frame = rdist.FrameSharder(r, W, H, rank, n, force_gather=force_dist, pipeline=os.environ.get("RPT_DIST_PIPELINE", "1") != "0")   # allocates outputs; N == 1 renders straight into the framebuffer
 
+    animate = os.environ.get("RPT_BENCH_ANIMATE") == "1"     # rehearsal only: every frame differs (camera clock runs)
+    clock = [t]
+
     def step():
+        if animate:
+            clock[0] += 0.016
+            scene.set_camera(vel, clock[0])
+            scene.update_objects()
         r.set_objects(scene)            # per-frame Object[] refresh, as the reference does
         frame.render_and_gather()       # kernel (+ RCCL gather + root scatter when N > 1)
 

@@ -91,6 +91,12 @@ class FrameSharder:
         self.exchange = world > 1 or force_gather      # force_gather: run the plane/gather/scatter path with one rank
         self.depth = 2 if pipeline else 1
         self.frame = 0
+        # The render kernels, the tensors below and what RCCL synchronises with must share ONE real stream.  torch's
+        # default stream has handle 0, which the C-ABI reads as "the context's own stream": never use it here.
+        self.stream = torch.cuda.current_stream()
+        if self.stream.cuda_stream == 0:
+            self.stream = torch.cuda.Stream(device=dev)
+        renderer.set_stream(self.stream.cuda_stream)
         if not self.exchange:
             renderer.set_rows(0, 1, False)
             self.framebuffer = torch.zeros(width * height * 4, dtype=torch.int32, device=dev)
@@ -107,6 +113,11 @@ class FrameSharder:
             self.scattered = [None] * self.depth    # event: reassembly of the frame that last used gathered slot i
 
     def render_and_gather(self):
+        import torch
+        with torch.cuda.stream(self.stream):
+            self._render_and_gather()
+
+    def _render_and_gather(self):
         if not self.exchange:
             self.r.render_async()
             return
