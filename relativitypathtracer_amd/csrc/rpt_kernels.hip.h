@@ -298,6 +298,19 @@ RPT_DEV bool intersect_triangle_edges(f3 A, f3 v0v1, f3 v0v2, const Ray &ray, fl
     return true;
 }
 
+struct DTriRec { f3 A, v0v1, v0v2; int id; };
+
+RPT_DEV DTriRec load_dtri(const KernelArgs &a, int k) {
+    const v4f *p = reinterpret_cast<const v4f *>(a.dtris + k);
+    const v4f t0 = p[0], t1 = p[1], t2 = p[2];
+    DTriRec r;
+    r.A = mk3(t0.x, t0.y, t0.z);
+    r.v0v1 = mk3(t0.w, t1.x, t1.y);
+    r.v0v2 = mk3(t1.z, t1.w, t2.x);
+    r.id = __float_as_int(t2.y);
+    return r;
+}
+
 // opencl_kernel.cl:200-308 from the point where the ray is in object space.  newRay = object-space
 // ray (direction normalised); world_origin/world_dirlen are ray->origin.yzw and |ray->dir.yzw|.
 // Diagnostic cycle accounting (V == 4 only): per wave, shader-clock cycles and wave-level iteration counts of
@@ -402,6 +415,28 @@ RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &
         }
         const int trisIndex = node.tri_begin(a);
         const int trisEnd = trisIndex + node.tri_count(a);
+        if (V == 11) {
+            // the leaf's records are consecutive: request record k+1 before record k is tested, alternating between two
+            // register sets so that no copy (and with it no wait) sits between the request and the test it overlaps
+            int k = trisIndex;
+            if (k < trisEnd) {
+                DTriRec ra = load_dtri(a, k), rb;
+                while (true) {
+                    rb = load_dtri(a, k + 1 < trisEnd ? k + 1 : k);
+                    float dist;
+                    f2 triUV;
+                    if (intersect_triangle_edges(ra.A, ra.v0v1, ra.v0v2, newRay, dist, triUV) && 0 <= dist && dist < hit.dist) {
+                        hitTri = ra.id; hit.dist = dist; hit.uv = triUV; didHit = true;
+                    }
+                    if (++k >= trisEnd) break;
+                    ra = load_dtri(a, k + 1 < trisEnd ? k + 1 : k);
+                    if (intersect_triangle_edges(rb.A, rb.v0v1, rb.v0v2, newRay, dist, triUV) && 0 <= dist && dist < hit.dist) {
+                        hitTri = rb.id; hit.dist = dist; hit.uv = triUV; didHit = true;
+                    }
+                    if (++k >= trisEnd) break;
+                }
+            }
+        } else
         for (int i = trisIndex; i < trisEnd; i++) {
             f3 A, v0v1, v0v2;
             int tri;
@@ -460,19 +495,6 @@ RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &
 //   * triangle records of a leaf are contiguous: record k+1 is requested before record k is tested.
 // Per leaf step the only loads left on the critical path are the descent levels.  Arithmetic and the
 // order of hit updates are those of octree_core (the break test still sees the leaf's final hit.dist).
-struct DTriRec { f3 A, v0v1, v0v2; int id; };
-
-RPT_DEV DTriRec load_dtri(const KernelArgs &a, int k) {
-    const v4f *p = reinterpret_cast<const v4f *>(a.dtris + k);
-    const v4f t0 = p[0], t1 = p[1], t2 = p[2];
-    DTriRec r;
-    r.A = mk3(t0.x, t0.y, t0.z);
-    r.v0v1 = mk3(t0.w, t1.x, t1.y);
-    r.v0v2 = mk3(t1.z, t1.w, t2.x);
-    r.id = __float_as_int(t2.y);
-    return r;
-}
-
 // Two triangles of a leaf at once, without branches: both Moller-Trumbore chains are independent and
 // interleave (ILP for a wave that is alone on its SIMD), and the six record loads are one round trip.
 // Accept/reject and the update order are those of the sequential loop (first `a`, then `b`).
@@ -1057,11 +1079,11 @@ RPT_DEV void render_pixel_body(const KernelArgs &a, const RowOrder *order = null
     f3 mapped = mk3(a.bg_mapped[0], a.bg_mapped[1], a.bg_mapped[2]);
     uint32_t packed = a.bg_packed;
     unsigned long long object_mask = ~0ull;
-    if (V == 10) {   // per-tile object mask of the binning prepass, natural dispatch order
+    if (V == 10 || V == 11) {   // per-tile object mask of the binning prepass, natural dispatch order
         const int tile = __builtin_amdgcn_readfirstlane(tile_row * a.tiles_x + (int)blockIdx.x * 4 + wave);
         object_mask = a.tile_masks[tile];
     }
-    if (V != 10 || object_mask != 0 || a.object_count > 64) {
+    if ((V != 10 && V != 11) || object_mask != 0 || a.object_count > 64) {
         const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);
         if (trace<V>(a, camdir, object_mask, color)) packed = tonemap_pack(a, color, mapped);
     }
@@ -1116,6 +1138,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_half(const KernelArgs a) { render_pixel_body<1, 1>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_quarter(const KernelArgs a) { render_pixel_body<1, 2>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_masked(const KernelArgs a) { render_pixel_body<10>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_masked_pf(const KernelArgs a) { render_pixel_body<11>(a); }
+__global__ __launch_bounds__(256) void rpt_render_kernel_v1_masked_pf_w3(const KernelArgs a) { render_pixel_body<11>(a); }
 __global__ __launch_bounds__(256) void rpt_render_kernel_primary_only(const KernelArgs a) { render_pixel_body<3>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_primary_only_w6(const KernelArgs a) { render_pixel_body<3>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_primary_only_w8(const KernelArgs a) { render_pixel_body<3>(a); }
