@@ -206,7 +206,7 @@ def main():
             "kernel_ms": round(kernel_ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "rpt_render_kernel_v1_masked (+ rpt_tile_bin_kernel prepass)", "algorithmic_bytes_per_launch": alg,
+                         "kernel": "rpt_render_kernel_v1_masked_w5 (+ rpt_tile_bin_kernel prepass)", "algorithmic_bytes_per_launch": alg,
                          "note": "16 B/pixel written + 320 B/object read per launch (SURVEY.md §8d); the path is "
                                  "latency/VALU-bound by construction, HBM fraction reported because it is the contract"},
         }

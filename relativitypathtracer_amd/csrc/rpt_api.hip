@@ -397,8 +397,8 @@ int launch(rpt_ctx *ctx) {
         a.row_cost = row_cost_dev;
     }
     // variant 0 = default: the derived-layout per-pixel kernel in natural dispatch order with the per-tile object
-    // masks of the prepass (25) when the octree allows the derived layout, else the general kernel (1)
-    int v = ctx->variant == 0 ? 25 : ctx->variant;
+    // masks of the prepass, 5 waves per SIMD (26) when the octree allows the derived layout, else the general kernel (1)
+    int v = ctx->variant == 0 ? 26 : ctx->variant;
     if (!ctx->compact_ok) v = 1;
     switch (v) {
     case 1: hipLaunchKernelGGL(rptd::rpt_render_kernel_v0, grid, dim3(256), 0, ctx->stream, a); break;
@@ -470,8 +470,11 @@ int launch(rpt_ctx *ctx) {
     case 20: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_half, dim3(grid.x, grid.y * 2), dim3(256), 0, ctx->stream, a); break;
     case 21: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_quarter, dim3((ctx->width + 15) / 16, grid.y * 2), dim3(256), 0, ctx->stream, a); break;
     case 25:
+    case 26:
+    case 27:
     case 28:
-    case 29: {   // natural order, per-tile object masks from the prepass (no lists)
+    case 29:
+    case 30: {   // natural order, per-tile object masks from the prepass (no lists)
         const int tiles_x = ((ctx->width + 31) / 32) * 4;          // tiles per row as the 32-pixel-wide blocks see them
         const int n_tiles = tiles_x * tiles;
         if (int rc = reserve(ctx, ctx->tile_masks, (size_t)n_tiles * 8)) return rc;
@@ -483,6 +486,9 @@ int launch(rpt_ctx *ctx) {
         a.mesh_object_bits = 0;
         hipLaunchKernelGGL(rptd::rpt_tile_bin_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, ctx->stream, a);
         if (v == 25) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked, grid, dim3(256), 0, ctx->stream, a);
+        else if (v == 26) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_w5, grid, dim3(256), 0, ctx->stream, a);
+        else if (v == 27) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_w6, grid, dim3(256), 0, ctx->stream, a);
+        else if (v == 30) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_pf_w5, grid, dim3(256), 0, ctx->stream, a);
         else if (v == 28) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_pf, grid, dim3(256), 0, ctx->stream, a);
         else hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_pf_w3, grid, dim3(256), 0, ctx->stream, a);
         break;
@@ -678,7 +684,7 @@ int rpt_set_debug_rgb(rpt_ctx *ctx, void *p) {
 }
 
 int rpt_set_variant(rpt_ctx *ctx, int variant) {
-    if (!ctx || variant < 0 || variant > 29) return RPT_ERR_ARG;
+    if (!ctx || variant < 0 || variant > 30) return RPT_ERR_ARG;
     ctx->variant = variant;
     return RPT_OK;
 }

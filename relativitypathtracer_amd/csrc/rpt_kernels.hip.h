@@ -1140,6 +1140,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_masked(const KernelArgs a) { render_pixel_body<10>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_masked_pf(const KernelArgs a) { render_pixel_body<11>(a); }
 __global__ __launch_bounds__(256) void rpt_render_kernel_v1_masked_pf_w3(const KernelArgs a) { render_pixel_body<11>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_v1_masked_w5(const KernelArgs a) { render_pixel_body<10>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_v1_masked_w6(const KernelArgs a) { render_pixel_body<10>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_v1_masked_pf_w5(const KernelArgs a) { render_pixel_body<11>(a); }
 __global__ __launch_bounds__(256) void rpt_render_kernel_primary_only(const KernelArgs a) { render_pixel_body<3>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_primary_only_w6(const KernelArgs a) { render_pixel_body<3>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_primary_only_w8(const KernelArgs a) { render_pixel_body<3>(a); }
