@@ -10,6 +10,12 @@ does every frame, Render.cpp:202) + render every pixel; with N > 1 each rank ren
 and a root-side kernel expands them into the 16 B/pixel framebuffer.  Scene buffers are resident in
 HBM before the timed region; the framebuffer stays in device memory (the reference never reads back).
 
+Frames in flight (--inflight, default 3): a frame's critical path is the serial octree walk of its dearest pixel,
+which leaves most of the GPU idle for most of one frame; consecutive frames are therefore submitted on separate
+streams (one context per slot) and overlap on the device.  Every frame is still refreshed, rendered completely
+and kept in its slot's framebuffer; `value` is frames/second x pixels over the K timed steps.  The same frames
+one at a time (the reference's blocking runKernel) are timed right after and reported as `one_frame_at_a_time`.
+
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
@@ -98,6 +104,8 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("RPT_FRAMES_IN_FLIGHT", "3")),
+                    help="frames in flight (contexts on concurrent streams); 1 = one frame at a time, as the reference's runKernel()")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="after timing, compare rank 0's framebuffer with the oracle on a few row bands")
     ap.add_argument("--gather", default="plane4", choices=["plane4"], help="what is gathered with N>1 (4 B/pixel colour plane)")
@@ -132,16 +140,18 @@ def main():
     scene.update_objects()
     n_objects = scene.desc().object_count
 
-    r = Renderer(local_rank)
-    # a real (non-null) stream for everything: the render kernels, torch's tensor ops and what RCCL synchronises
-    # with must be ONE stream — torch's default stream has handle 0, which the C-ABI reads as "the context's own stream"
-    stream = torch.cuda.Stream(device=torch.device("cuda", local_rank))
-    torch.cuda.set_stream(stream)
-    r.set_stream(stream.cuda_stream)
-    r.upload_scene(scene)
-    r.set_scene_params(scene, W, H)
-    r.set_variant(args.variant)
-    frame = rdist.FrameSharder(r, W, H, rank, n, force_gather=force_dist, pipeline=os.environ.get("RPT_DIST_PIPELINE", "1") != "0")   # allocates outputs; N == 1 renders straight into the framebuffer
+    # frames in flight: one context per slot, each on its own stream (dist.FrameSharder), scene resident in each
+    pipeline = os.environ.get("RPT_DIST_PIPELINE", "1") != "0"
+    inflight = max(1, args.inflight) if pipeline else 1
+    renderers = []
+    for _ in range(inflight):
+        rr = Renderer(local_rank)
+        rr.upload_scene(scene)
+        rr.set_scene_params(scene, W, H)
+        rr.set_variant(args.variant)
+        renderers.append(rr)
+    r = renderers[0]
+    frame = rdist.FrameSharder(renderers, W, H, rank, n, force_gather=force_dist, pipeline=pipeline)   # allocates outputs; N == 1 renders straight into the framebuffers
 
     animate = os.environ.get("RPT_BENCH_ANIMATE") == "1"     # rehearsal only: every frame differs (camera clock runs)
     clock = [t]
@@ -151,8 +161,8 @@ def main():
             clock[0] += 0.016
             scene.set_camera(vel, clock[0])
             scene.update_objects()
-        r.set_objects(scene)            # per-frame Object[] refresh, as the reference does
-        frame.render_and_gather()       # kernel (+ RCCL gather + root scatter when N > 1)
+        # per-frame Object[] refresh (as the reference does) + kernel (+ RCCL gather + root scatter when N > 1)
+        frame.render_and_gather(scene)
 
     def barrier():
         torch.cuda.synchronize()
@@ -160,19 +170,49 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
+    import ctypes as C
+
+    def timed(steps):
+        """K steps bracketed by barrier + device sync; returns (wall s, mean launch ms, sum of launch ms) of this rank."""
+        for rr in renderers:
+            rr._check(rr._lib.rpt_timing_begin(rr._h, steps), "rpt_timing_begin")
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        submit = time.perf_counter() - t0
+        barrier()
+        wall = time.perf_counter() - t0
+        if rank == 0 and os.environ.get("RPT_BENCH_VERBOSE") == "1":
+            print(f"[bench] host submission {submit / steps * 1e3:.4f} ms/step, wall {wall / steps * 1e3:.4f} ms/step", file=sys.stderr)
+        total, count = 0.0, 0
+        for rr in renderers:
+            tot, nfr = C.c_float(), C.c_int()
+            rr._check(rr._lib.rpt_timing_end(rr._h, C.byref(tot), C.byref(nfr)), "rpt_timing_end")
+            total += tot.value
+            count += nfr.value
+        return wall, total / max(count, 1), total
+
     for _ in range(max(args.warmup, 0)):
         step()
-    barrier()
-    r._check(r._lib.rpt_timing_begin(r._h, args.steps), "rpt_timing_begin")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    import ctypes as C
-    tot, nfr = C.c_float(), C.c_int()
-    r._check(r._lib.rpt_timing_end(r._h, C.byref(tot), C.byref(nfr)), "rpt_timing_end")
-    kernel_ms = tot.value / max(nfr.value, 1)     # average render-kernel duration on this rank, HIP events
+    elapsed, kernel_ms, kernel_sum_ms = timed(args.steps)     # launch duration: HIP events on the launch's own stream
+
+    # the same frames one at a time (submit, wait, submit ...: what the reference's blocking runKernel() does) — the
+    # frame LATENCY, and the launch duration without other launches sharing the device
+    blocking_ms = blocking_kernel_ms = None
+    if n == 1 and not force_dist:
+        nb = max(1, min(args.steps, 30))
+        barrier()
+        r._check(r._lib.rpt_timing_begin(r._h, nb), "rpt_timing_begin")
+        t0 = time.perf_counter()
+        for _ in range(nb):
+            frame.slots[0].r.set_objects(scene)
+            frame.slots[0].r.render()
+        blocking_ms = (time.perf_counter() - t0) / nb * 1e3
+        tot, nfr = C.c_float(), C.c_int()
+        r._check(r._lib.rpt_timing_end(r._h, C.byref(tot), C.byref(nfr)), "rpt_timing_end")
+        blocking_kernel_ms = tot.value / max(nfr.value, 1)
+        frame.last = frame.slots[0]
 
     if n > 1:
         tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
@@ -190,7 +230,11 @@ def main():
             alg = algorithmic_bytes(W, H, n_objects)
         else:
             alg = 4 * W * frame.local_rows + 320 * n_objects
-        achieved = alg / (kernel_ms * 1e-3) / 1e9
+        # Launches of consecutive frames overlap on the device: `overlap` = sum of launch durations / wall time of
+        # the region = average number of launches running at once.  A launch's share of the device is then
+        # duration / overlap, and achieved = bytes per launch / that (= bytes of all launches / wall time).
+        overlap = max(1.0, kernel_sum_ms / (elapsed * 1e3)) if frame.depth > 1 else 1.0
+        achieved = alg / (kernel_ms / overlap * 1e-3) / 1e9
         out = {
             "metric": "Mrays/s (primary rays) on Scenes/bunny.txt at 3840x2160" if (args.workload, W, H) == ("bunny", 3840, 2160)
                       else f"Mrays/s (primary rays) on Scenes/{scene_name}.txt at {W}x{H}",
@@ -200,13 +244,21 @@ def main():
             "config": {"workload": f"Scenes/{scene_name}.txt {W}x{H}, camera v={list(vel)} t={t}, interval={scene.params['interval']}, "
                                    f"mesh=Models/bunny.obj (StanfordBunny.obj is missing from the reference)" if scene_name == "bunny"
                        else f"Scenes/{scene_name}.txt {W}x{H}, camera v={list(vel)} t={t}",
-                       "frame": "rpt_set_objects + render kernel" + (" + RCCL gather(4 B/px plane) + root scatter, frames overlapped two deep" if n > 1 else ""),
+                       "frame": "rpt_set_objects + render kernel" + (" + RCCL gather(4 B/px plane) + root scatter" if n > 1 else ""),
+                       "frames_in_flight": frame.depth,
                        "sharding": "interleaved 8-row tiles, tile k -> rank k mod N" if n > 1 else "none",
                        "variant": args.variant},
             "kernel_ms": round(kernel_ms, 4),
+            "one_frame_at_a_time": None if blocking_ms is None else {
+                "ms_per_frame": round(blocking_ms, 4), "value": round(W * H / blocking_ms / 1e3, 2), "kernel_ms": round(blocking_kernel_ms, 4),
+                "note": "submit, wait, submit ... like the reference's blocking runKernel(): the frame latency"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel": "rpt_render_kernel_v1_masked_w5 (+ rpt_tile_bin_kernel prepass)", "algorithmic_bytes_per_launch": alg,
+                         "launch_ms": round(kernel_ms, 4), "launches_overlapped": round(overlap, 3),
+                         "definition": "achieved = algorithmic_bytes_per_launch / (launch_ms / launches_overlapped): launch_ms is the mean "
+                                       "HIP-event duration of one launch on its own stream (what rocprofv3 reports per dispatch), "
+                                       "launches_overlapped the mean number of launches sharing the device in the timed region",
                          "note": "16 B/pixel written + 320 B/object read per launch (SURVEY.md §8d); the path is "
                                  "latency/VALU-bound by construction, HBM fraction reported because it is the contract"},
         }
@@ -220,22 +272,30 @@ def main():
                 out["roofline"]["traffic_source"] = "profiles/r01_final_bunny4k_pmc_summary.json (rocprofv3 --pmc, same command)"
             except Exception:
                 pass
+        if blocking_kernel_ms:
+            a1 = alg / (blocking_kernel_ms * 1e-3) / 1e9
+            out["roofline"]["single_launch"] = {"launch_ms": round(blocking_kernel_ms, 4), "achieved": round(a1, 2),
+                                                "frac": round(a1 / HBM_PEAK_GBS, 5), "note": "one launch at a time, nothing overlapped"}
         if not args.no_cpu_baseline and n == 1:
             out["cpu_baseline"] = cpu_baseline(scene, W, H)
         if args.check:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_ffi
-            fb = frame.framebuffer.cpu().numpy().view(np.uint8).reshape(H, W, 16)
+            # every framebuffer that received frames: the root's, or (no exchange) the one of each slot in flight
+            fbs = [frame.framebuffer] if frame.exchange else [sl.framebuffer for sl in frame.slots]
+            fbs = [f.cpu().numpy().view(np.uint8).reshape(H, W, 16) for f in fbs]
             ok = True
             for (r0, r1) in [(0, 8), (H * 2 // 5, H * 2 // 5 + 16), (H // 2, H // 2 + 16), (H - 8, H)]:
                 opx, _, _ = oracle_ffi.render(scene, W, H, rows=(r0, r1), want_rgb=False)
-                ok = ok and np.array_equal(fb[r0:r1, :, 8:12], opx["rgba"].reshape(H, W, 4)[r0:r1])
+                for fb in fbs:
+                    ok = ok and np.array_equal(fb[r0:r1, :, 8:12], opx["rgba"].reshape(H, W, 4)[r0:r1])
             out["check"] = "framebuffer rows identical to the oracle" if ok else "MISMATCH vs oracle"
         print(json.dumps(out), flush=True)
     if n > 1 or force_dist:
         td.barrier()
         td.destroy_process_group()
-    r.close()
+    for rr in renderers:
+        rr.close()
 
 
 if __name__ == "__main__":

@@ -474,7 +474,8 @@ int launch(rpt_ctx *ctx) {
     case 27:
     case 28:
     case 29:
-    case 30: {   // natural order, per-tile object masks from the prepass (no lists)
+    case 30:
+    case 31: {   // natural order, per-tile object masks from the prepass (no lists)
         const int tiles_x = ((ctx->width + 31) / 32) * 4;          // tiles per row as the 32-pixel-wide blocks see them
         const int n_tiles = tiles_x * tiles;
         if (int rc = reserve(ctx, ctx->tile_masks, (size_t)n_tiles * 8)) return rc;
@@ -489,6 +490,7 @@ int launch(rpt_ctx *ctx) {
         else if (v == 26) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_w5, grid, dim3(256), 0, ctx->stream, a);
         else if (v == 27) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_w6, grid, dim3(256), 0, ctx->stream, a);
         else if (v == 30) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_pf_w5, grid, dim3(256), 0, ctx->stream, a);
+        else if (v == 31) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_pipe_w4, grid, dim3(256), 0, ctx->stream, a);
         else if (v == 28) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_pf, grid, dim3(256), 0, ctx->stream, a);
         else hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_pf_w3, grid, dim3(256), 0, ctx->stream, a);
         break;
@@ -684,7 +686,7 @@ int rpt_set_debug_rgb(rpt_ctx *ctx, void *p) {
 }
 
 int rpt_set_variant(rpt_ctx *ctx, int variant) {
-    if (!ctx || variant < 0 || variant > 30) return RPT_ERR_ARG;
+    if (!ctx || variant < 0 || variant > 31) return RPT_ERR_ARG;
     ctx->variant = variant;
     return RPT_OK;
 }

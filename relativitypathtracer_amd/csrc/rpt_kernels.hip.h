@@ -850,7 +850,7 @@ RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, H
         Ray newRay;
         newRay.origin = origin;
         newRay.dir = dir;
-        if (V == 6) return octree_core_pipelined(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
+        if (V == 6 || V == 12) return octree_core_pipelined(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
         if (V == 8) return octree_core_packet(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
         return octree_core<V>(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
     }
@@ -881,7 +881,7 @@ RPT_DEV bool intersect_object_primary(const KernelArgs &a, int i, f4 rayDir, Hit
         newRay.origin = origin;
         newRay.dir = dir;
         const f3 cam3 = mk3(obj.stationaryCam.y, obj.stationaryCam.z, obj.stationaryCam.w);
-        if (V == 6) return octree_core_pipelined(a, obj, newRay, cam3, length(d3), hit);
+        if (V == 6 || V == 12) return octree_core_pipelined(a, obj, newRay, cam3, length(d3), hit);
         if (V == 8) return octree_core_packet(a, obj, newRay, cam3, length(d3), hit);
         return octree_core<V>(a, obj, newRay, cam3, length(d3), hit);
     }
@@ -1079,11 +1079,11 @@ RPT_DEV void render_pixel_body(const KernelArgs &a, const RowOrder *order = null
     f3 mapped = mk3(a.bg_mapped[0], a.bg_mapped[1], a.bg_mapped[2]);
     uint32_t packed = a.bg_packed;
     unsigned long long object_mask = ~0ull;
-    if (V == 10 || V == 11) {   // per-tile object mask of the binning prepass, natural dispatch order
+    if (V == 10 || V == 11 || V == 12) {   // per-tile object mask of the binning prepass, natural dispatch order
         const int tile = __builtin_amdgcn_readfirstlane(tile_row * a.tiles_x + (int)blockIdx.x * 4 + wave);
         object_mask = a.tile_masks[tile];
     }
-    if ((V != 10 && V != 11) || object_mask != 0 || a.object_count > 64) {
+    if ((V != 10 && V != 11 && V != 12) || object_mask != 0 || a.object_count > 64) {
         const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);
         if (trace<V>(a, camdir, object_mask, color)) packed = tonemap_pack(a, color, mapped);
     }
@@ -1143,6 +1143,7 @@ __global__ __launch_bounds__(256) void rpt_render_kernel_v1_masked_pf_w3(const K
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_v1_masked_w5(const KernelArgs a) { render_pixel_body<10>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_v1_masked_w6(const KernelArgs a) { render_pixel_body<10>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_v1_masked_pf_w5(const KernelArgs a) { render_pixel_body<11>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_masked_pipe_w4(const KernelArgs a) { render_pixel_body<12>(a); }
 __global__ __launch_bounds__(256) void rpt_render_kernel_primary_only(const KernelArgs a) { render_pixel_body<3>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_primary_only_w6(const KernelArgs a) { render_pixel_body<3>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_primary_only_w8(const KernelArgs a) { render_pixel_body<3>(a); }

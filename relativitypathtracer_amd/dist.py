@@ -71,82 +71,117 @@ def reassemble_planes(planes: np.ndarray, width: int, height: int, world: int) -
     return out
 
 
+class _Slot:
+    """One frame in flight: a context (rpt_ctx) on its own stream with its own output buffers."""
+    __slots__ = ("r", "stream", "framebuffer", "plane", "gathered", "work", "scattered")
+
+
 class FrameSharder:
     """Owns the output tensors of one rank and runs render (+ gather + scatter) frame after frame.
 
-    With more than one rank the three stages of a frame run on different queues — render on the launch
-    stream, the gather on RCCL's stream, the root's reassembly on a side stream — and consecutive frames
-    overlap two deep (double-buffered planes): frame k+1 renders while frame k's plane is on the wire.
+    Frames in flight.  A frame's critical path is the serial octree walk of its dearest pixel, so
+    one frame alone leaves most of the GPU idle for most of its duration.  The sharder therefore keeps
+    ``len(renderers)`` frames in flight: every slot is a context of its own (scene resident once per context) on
+    its own stream with its own output buffers, frame f runs in slot ``f mod depth``, and kernels of consecutive
+    frames overlap on the device.  Each frame still gets its own ``rpt_set_objects`` (the host may change
+    ``Object[]`` between any two frames) and is rendered completely; ``framebuffer`` is the last submitted frame.
+
+    With more than one rank the three stages of a frame run on different queues — render on the slot's
+    stream, the gather on RCCL's stream, the root's reassembly on a side stream — with per-slot planes.
     Per frame every rank still issues exactly one collective, in the same order on all ranks; the host
     never blocks (buffer reuse is ordered by stream-level waits only).
     """
 
-    def __init__(self, renderer, width: int, height: int, rank: int, world: int, force_gather: bool = False,
+    def __init__(self, renderers, width: int, height: int, rank: int, world: int, force_gather: bool = False,
                  pipeline: bool = True):
         import torch
-        self.r, self.W, self.H, self.rank, self.world = renderer, width, height, rank, world
+        if not isinstance(renderers, (list, tuple)):
+            renderers = [renderers]
+        if not pipeline:
+            renderers = renderers[:1]
+        self.W, self.H, self.rank, self.world = width, height, rank, world
         dev = torch.device("cuda", torch.cuda.current_device())
-        self.framebuffer: Optional["torch.Tensor"] = None
         self.local_rows = local_tile_count(height, rank, world) * TILE_ROWS
         self.exchange = world > 1 or force_gather      # force_gather: run the plane/gather/scatter path with one rank
-        self.depth = 2 if pipeline else 1
+        self.depth = len(renderers)
+        self.pipeline = pipeline
         self.frame = 0
-        # The render kernels, the tensors below and what RCCL synchronises with must share ONE real stream.  torch's
-        # default stream has handle 0, which the C-ABI reads as "the context's own stream": never use it here.
-        self.stream = torch.cuda.current_stream()
-        if self.stream.cuda_stream == 0:
-            self.stream = torch.cuda.Stream(device=dev)
-        renderer.set_stream(self.stream.cuda_stream)
-        if not self.exchange:
-            renderer.set_rows(0, 1, False)
-            self.framebuffer = torch.zeros(width * height * 4, dtype=torch.int32, device=dev)
-            renderer.set_output(self.framebuffer.data_ptr())
-            return
+        self.last = None
+        self.slots = []
         words = plane_words(width, height, world)
-        renderer.set_rows(rank, world, True)
-        self.planes = [torch.zeros(words, dtype=torch.int32, device=dev) for _ in range(self.depth)]
-        self.works = [None] * self.depth            # gather of the frame that last used plane slot i
-        if rank == 0:
-            self.gathered = [torch.zeros((world, words), dtype=torch.int32, device=dev) for _ in range(self.depth)]
-            self.framebuffer = torch.zeros(width * height * 4, dtype=torch.int32, device=dev)
+        for r in renderers:
+            s = _Slot()
+            s.r = r
+            # The render kernels, the tensors below and what RCCL synchronises with must share ONE real stream per
+            # slot.  torch's default stream has handle 0, which the C-ABI reads as "the context's own stream": never it.
+            s.stream = torch.cuda.Stream(device=dev)
+            r.set_stream(s.stream.cuda_stream)
+            s.framebuffer = s.plane = s.gathered = s.work = s.scattered = None
+            if not self.exchange:
+                r.set_rows(0, 1, False)
+                s.framebuffer = torch.zeros(width * height * 4, dtype=torch.int32, device=dev)
+                r.set_output(s.framebuffer.data_ptr())
+            else:
+                r.set_rows(rank, world, True)
+                s.plane = torch.zeros(words, dtype=torch.int32, device=dev)
+                r.set_plane_output(s.plane.data_ptr())
+                if rank == 0:
+                    s.gathered = torch.zeros((world, words), dtype=torch.int32, device=dev)
+            self.slots.append(s)
+        self.r = self.slots[0].r
+        self._root_fb = None
+        self.side = None
+        if self.exchange and rank == 0:
+            self._root_fb = torch.zeros(width * height * 4, dtype=torch.int32, device=dev)
             self.side = torch.cuda.Stream(device=dev) if pipeline else None
-            self.scattered = [None] * self.depth    # event: reassembly of the frame that last used gathered slot i
 
-    def render_and_gather(self):
+    @property
+    def framebuffer(self):
+        """Device tensor holding the most recently submitted frame (16 B/pixel); complete after a device sync."""
+        if self.exchange:
+            return self._root_fb
+        return (self.last or self.slots[0]).framebuffer
+
+    def render_and_gather(self, objects=None):
+        """Submit one frame: Object[] refresh (if given: a Scene or raw bytes), render, and with N > 1 the exchange."""
         import torch
-        with torch.cuda.stream(self.stream):
-            self._render_and_gather()
-
-    def _render_and_gather(self):
-        if not self.exchange:
-            self.r.render_async()
+        slot = self.slots[self.frame % self.depth]
+        self.frame += 1
+        self.last = slot
+        if not self.exchange:                 # the context launches on the slot's stream itself: no torch state to switch
+            if objects is not None:
+                slot.r.set_objects(objects)
+            slot.r.render_async()
             return
+        with torch.cuda.stream(slot.stream):
+            if objects is not None:
+                slot.r.set_objects(objects)
+            self._render_and_gather(slot)
+
+    def _render_and_gather(self, slot):
         import torch
         import torch.distributed as td
-        slot = self.frame % self.depth
-        self.frame += 1
         cur = torch.cuda.current_stream()
-        if self.works[slot] is not None:
-            self.works[slot].wait()                 # stream-level: this plane slot has left the GPU
-        if self.rank == 0 and self.scattered[slot] is not None:
-            cur.wait_event(self.scattered[slot])    # this gather slot has been consumed by the reassembly
-        self.r.set_plane_output(self.planes[slot].data_ptr())
-        self.r.render_async()
-        glist = list(self.gathered[slot].unbind(0)) if self.rank == 0 else None
-        work = td.gather(self.planes[slot], glist, dst=0, async_op=True)      # the one exchange step of the frame
-        self.works[slot] = work
+        if slot.work is not None:
+            slot.work.wait()                        # stream-level: this slot's plane has left the GPU
+        if self.rank == 0 and slot.scattered is not None:
+            cur.wait_event(slot.scattered)          # this slot's gather buffer has been consumed by the reassembly
+        slot.r.render_async()
+        glist = list(slot.gathered.unbind(0)) if self.rank == 0 else None
+        work = td.gather(slot.plane, glist, dst=0, async_op=True)      # the one exchange step of the frame
+        slot.work = work
         if self.rank == 0:
             if self.side is None:
                 work.wait()
-                self.r.scatter_colour_plane(self.gathered[slot].data_ptr(), self.framebuffer.data_ptr(), self.W, self.H,
-                                            self.world, self.gathered[slot].shape[1])
+                slot.r.scatter_colour_plane(slot.gathered.data_ptr(), self._root_fb.data_ptr(), self.W, self.H,
+                                            self.world, slot.gathered.shape[1])
             else:
                 with torch.cuda.stream(self.side):
                     work.wait()
-                    self.r.scatter_colour_plane(self.gathered[slot].data_ptr(), self.framebuffer.data_ptr(), self.W, self.H,
-                                                self.world, self.gathered[slot].shape[1], stream=self.side.cuda_stream)
+                    slot.r.scatter_colour_plane(slot.gathered.data_ptr(), self._root_fb.data_ptr(), self.W, self.H,
+                                                self.world, slot.gathered.shape[1], stream=self.side.cuda_stream)
                     ev = torch.cuda.Event()
                     ev.record(self.side)
-                    self.scattered[slot] = ev
-        elif self.depth == 1:
+                    slot.scattered = ev
+        elif not self.pipeline:
             work.wait()

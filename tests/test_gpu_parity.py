@@ -41,7 +41,7 @@ SIZES = {"cube": (640, 480), "arch": (480, 270), "arch_t0": (480, 270), "bunny":
 EXACT = {"cube", "arch", "arch_t0", "bunny", "shadows", "cubes", "rulers", "ladder"}
 
 
-VARIANTS = [0, 1, 2, 3, 4, 5, 6, 12, 13, 15, 16, 17, 18, 19, 20, 21, 25, 26, 27, 28, 29, 30]   # 0 = default; 1 = reference-layout kernel; 2..6 = derived-layout kernels; 12 = tile-binned
+VARIANTS = [0, 1, 2, 3, 4, 5, 6, 12, 13, 15, 16, 17, 18, 19, 20, 21, 25, 26, 27, 28, 29, 30, 31]   # 0 = default; 1 = reference-layout kernel; 2..6 = derived-layout kernels; 12 = tile-binned
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
