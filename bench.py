@@ -140,13 +140,16 @@ def main():
     scene.update_objects()
     n_objects = scene.desc().object_count
 
-    # frames in flight: one context per slot, each on its own stream (dist.FrameSharder), scene resident in each
+    # frames in flight: one context per slot, each on its own stream (dist.FrameSharder), one resident scene
     pipeline = os.environ.get("RPT_DIST_PIPELINE", "1") != "0"
     inflight = max(1, args.inflight) if pipeline else 1
     renderers = []
     for _ in range(inflight):
         rr = Renderer(local_rank)
-        rr.upload_scene(scene)
+        if renderers:
+            rr.share_scene(renderers[0])      # one resident copy of the scene for all frame slots
+        else:
+            rr.upload_scene(scene)
         rr.set_scene_params(scene, W, H)
         rr.set_variant(args.variant)
         renderers.append(rr)

@@ -12,6 +12,7 @@
  *
  *   rpt_create / rpt_destroy   initOpenCL()                        CLSetup.cpp:64-135
  *   rpt_upload_scene           8x cl::Buffer + enqueueWriteBuffer   main.cpp:33-55
+ *   rpt_share_scene            (none: the reference keeps one frame in flight)
  *   rpt_set_objects            per-frame write of Object[] + setArg(0)   Render.cpp:202-203
  *   rpt_set_params             initCLKernel() setArg 1,9..13; resize/interval re-binds
  *                                                                   CLSetup.cpp:150-163, Render.cpp:116-117,141
@@ -57,6 +58,15 @@ const char *rpt_last_error(const rpt_ctx *ctx);
 /* Upload the eight read-only scene arrays (copied; validated so that no index can leave its
  * array).  The Object[] in `scene` is taken as the first rpt_set_objects. */
 int rpt_upload_scene(rpt_ctx *ctx, const rpt_scene_desc *scene);
+
+/* Frames in flight (not in the reference, whose runKernel() finishes every frame before the next starts,
+ * CLSetup.cpp:167-191).  One frame's critical path is the serial octree walk of its dearest pixel, which leaves
+ * most of the GPU idle; a host that wants frame RATE keeps 2-3 frames in flight, one context per frame slot, each
+ * with its own stream and output, rendering frame f in slot f mod n (rpt_set_objects + rpt_render_async, and
+ * rpt_sync before the slot's output is consumed).  rpt_share_scene gives `ctx` the scene already resident in
+ * `owner` (same device) instead of a second copy: the geometry is reference-counted, so either context may be
+ * destroyed or given another scene at any time.  Object[] and the per-context settings are not shared. */
+int rpt_share_scene(rpt_ctx *ctx, rpt_ctx *owner);
 
 /* Refresh Object[] (count * 320 B, copied).  Called every frame by the reference's render(). */
 int rpt_set_objects(rpt_ctx *ctx, const void *objects, int count);

@@ -121,6 +121,7 @@ HIP_SYMBOLS = {
     "rpt_destroy": (None, [C.c_void_p]),
     "rpt_last_error": (C.c_char_p, [C.c_void_p]),
     "rpt_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
+    "rpt_share_scene": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rpt_set_objects": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rpt_set_params": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.c_int, C.c_int, C.c_int]),
     "rpt_set_output": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <algorithm>
 #include <functional>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -29,6 +30,23 @@ struct DeviceBuffer {
     size_t capacity = 0;
 };
 
+void release(DeviceBuffer &b);
+
+// The resident scene geometry: immutable between two rpt_upload_scene calls, so contexts that keep several frames
+// in flight share ONE copy (rpt_share_scene); the last context holding it frees it.
+struct Geometry {
+    int device = 0;
+    DeviceBuffer vertices, normals, uvs, triangles, octrees, octreeTris, textures;
+    DeviceBuffer dnodes, dtris;               // derived layouts (rpt_kernels.hip.h)
+    bool compact_ok = false;                  // derived octree layout usable (children consecutive)
+    std::vector<float> host_node_bounds;      // min.xyz,max.xyz per octree node (culling spheres of mesh roots)
+    size_t vertex_count = 0, normal_count = 0, uv_count = 0, triangle_words = 0, octree_count = 0, octree_tri_count = 0;
+    ~Geometry() {
+        (void)hipSetDevice(device);
+        for (DeviceBuffer *b : {&vertices, &normals, &uvs, &triangles, &octrees, &octreeTris, &textures, &dnodes, &dtris}) release(*b);
+    }
+};
+
 }  // namespace
 
 struct rpt_ctx {
@@ -38,7 +56,8 @@ struct rpt_ctx {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::string error;
 
-    DeviceBuffer objects, vertices, normals, uvs, triangles, octrees, octreeTris, textures;
+    DeviceBuffer objects;
+    std::shared_ptr<Geometry> geo;                    // never null
     DeviceBuffer counters, wave_times;
     DeviceBuffer row_cost;                            // per tile row: two alternating arrays of cycle counts
     unsigned int *host_row_cost = nullptr;            // pinned read-back of an earlier frame's row costs
@@ -51,16 +70,13 @@ struct rpt_ctx {
     unsigned int frame_parity = 0;
     DeviceBuffer tile_masks, bin_counts, bin_lists;   // tile binning (variant 12)
     std::vector<uint8_t> host_objects;                // last Object[] (DObj depends on `interval`: rebuilt when it changes)
-    std::vector<float> host_node_bounds;              // min.xyz,max.xyz per octree node (culling spheres of mesh roots)
-    DeviceBuffer dnodes, dtris, dobjs;        // derived layouts (rpt_kernels.hip.h)
-    bool compact_ok = false;                  // derived octree layout usable (children consecutive)
+    DeviceBuffer dobjs;
     DeviceBuffer owned_out, owned_plane, owned_rgb;
     void *pinned_objects = nullptr;                   // RPT_STAGING_SLOTS pinned slots of Object[] + DObj[]
     size_t pinned_capacity = 0;
     hipEvent_t staging_done[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned int staging_used = 0, staging_next = 0;
     int object_count = 0;
-    size_t vertex_count = 0, normal_count = 0, uv_count = 0, triangle_words = 0, octree_count = 0, octree_tri_count = 0;
     bool scene_uploaded = false;
 
     float white_point[3] = {1, 1, 1};
@@ -189,11 +205,11 @@ int validate_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
 // Only the numbers the reference stores (and B-A, C-A, which intersect_triangle would form from
 // them with the same IEEE subtraction) go in, so traversal results are unchanged.
 int build_derived_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
-    ctx->compact_ok = false;
+    ctx->geo->compact_ok = false;
     if (s.octree_count == 0) {
-        ctx->compact_ok = true;
-        if (int rc = reserve(ctx, ctx->dnodes, 0)) return rc;
-        return reserve(ctx, ctx->dtris, 0);
+        ctx->geo->compact_ok = true;
+        if (int rc = reserve(ctx, ctx->geo->dnodes, 0)) return rc;
+        return reserve(ctx, ctx->geo->dtris, 0);
     }
     std::vector<rptd::DNode> nodes(s.octree_count);
     std::vector<rptd::DTri> tris;
@@ -228,9 +244,9 @@ int build_derived_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
         }
     }
     if (tris.size() > (size_t)0x7fffffff) return RPT_OK;
-    if (int rc = upload(ctx, ctx->dnodes, nodes.data(), nodes.size() * sizeof(rptd::DNode))) return rc;
-    if (int rc = upload(ctx, ctx->dtris, tris.data(), tris.size() * sizeof(rptd::DTri))) return rc;
-    ctx->compact_ok = true;
+    if (int rc = upload(ctx, ctx->geo->dnodes, nodes.data(), nodes.size() * sizeof(rptd::DNode))) return rc;
+    if (int rc = upload(ctx, ctx->geo->dtris, tris.data(), tris.size() * sizeof(rptd::DTri))) return rc;
+    ctx->geo->compact_ok = true;
     return RPT_OK;
 }
 
@@ -269,8 +285,8 @@ void build_dobjs(const rpt_ctx *ctx, const rpt_object *objs, int count, rptd::DO
         float radius = -1.0f;
         if (o.type == RPT_SPHERE) radius = 1.0f;
         else if (o.type == RPT_CUBE) radius = 1.7320508f;
-        else if (o.type == RPT_MESH && (size_t)o.meshIndex * 6 + 5 < ctx->host_node_bounds.size()) {
-            const float *nb = &ctx->host_node_bounds[(size_t)o.meshIndex * 6];
+        else if (o.type == RPT_MESH && (size_t)o.meshIndex * 6 + 5 < ctx->geo->host_node_bounds.size()) {
+            const float *nb = &ctx->geo->host_node_bounds[(size_t)o.meshIndex * 6];
             d.cbx = 0.5f * (nb[0] + nb[3]); d.cby = 0.5f * (nb[1] + nb[4]); d.cbz = 0.5f * (nb[2] + nb[5]);
             const float ex = nb[3] - nb[0], ey = nb[4] - nb[1], ez = nb[5] - nb[2];
             radius = 0.5f * std::sqrt(ex * ex + ey * ey + ez * ez);
@@ -284,11 +300,11 @@ int validate_objects(rpt_ctx *ctx, const rpt_object *objs, int count) {
     for (int i = 0; i < count; i++) {
         const rpt_object &o = objs[i];
         if (o.type < RPT_SPHERE || o.type > RPT_MESH) return fail(ctx, RPT_ERR_SCENE, "object: unknown type");
-        if (o.type == RPT_MESH && (o.meshIndex < 0 || (size_t)o.meshIndex >= ctx->octree_count))
+        if (o.type == RPT_MESH && (o.meshIndex < 0 || (size_t)o.meshIndex >= ctx->geo->octree_count))
             return fail(ctx, RPT_ERR_SCENE, "object: meshIndex is not an octree node");
         if (o.textureIndex != -1) {
             if (o.textureIndex < 0 || o.textureWidth <= 0 || o.textureHeight <= 0 ||
-                (unsigned long long)o.textureIndex + 3ull * (unsigned long long)o.textureWidth * (unsigned long long)o.textureHeight > ctx->textures.bytes)
+                (unsigned long long)o.textureIndex + 3ull * (unsigned long long)o.textureWidth * (unsigned long long)o.textureHeight > ctx->geo->textures.bytes)
                 return fail(ctx, RPT_ERR_SCENE, "object: texture lies outside the texture pool");
         }
     }
@@ -327,18 +343,18 @@ int launch(rpt_ctx *ctx) {
 
     rptd::KernelArgs a;
     std::memset(&a, 0, sizeof a);
-    a.dnodes = (const rptd::DNode *)ctx->dnodes.ptr;
-    a.dtris = (const rptd::DTri *)ctx->dtris.ptr;
+    a.dnodes = (const rptd::DNode *)ctx->geo->dnodes.ptr;
+    a.dtris = (const rptd::DTri *)ctx->geo->dtris.ptr;
     a.dobjs = (const rptd::DObj *)((const char *)ctx->objects.ptr + (size_t)ctx->object_count * sizeof(rpt_object));
     a.objects = (const rpt_object *)ctx->objects.ptr;
-    a.vertices = (const rpt_float3 *)ctx->vertices.ptr;
-    a.normals = (const rpt_float3 *)ctx->normals.ptr;
-    a.uvs = (const rpt_float2 *)ctx->uvs.ptr;
-    a.triangles = (const uint32_t *)ctx->triangles.ptr;
-    a.octrees = (const rpt_octree *)ctx->octrees.ptr;
-    a.octreeTris = (const int32_t *)ctx->octreeTris.ptr;
-    a.textures = (const uint8_t *)ctx->textures.ptr;
-    a.texture_bytes = (long long)ctx->textures.bytes;
+    a.vertices = (const rpt_float3 *)ctx->geo->vertices.ptr;
+    a.normals = (const rpt_float3 *)ctx->geo->normals.ptr;
+    a.uvs = (const rpt_float2 *)ctx->geo->uvs.ptr;
+    a.triangles = (const uint32_t *)ctx->geo->triangles.ptr;
+    a.octrees = (const rpt_octree *)ctx->geo->octrees.ptr;
+    a.octreeTris = (const int32_t *)ctx->geo->octreeTris.ptr;
+    a.textures = (const uint8_t *)ctx->geo->textures.ptr;
+    a.texture_bytes = (long long)ctx->geo->textures.bytes;
     a.out16 = ctx->colour_plane ? nullptr : (rpt_pixel *)(ctx->external_out ? ctx->external_out : ctx->owned_out.ptr);
     a.plane = ctx->colour_plane ? (uint32_t *)(ctx->external_plane ? ctx->external_plane : ctx->owned_plane.ptr) : nullptr;
     a.debug_rgb = (float *)(ctx->external_rgb ? ctx->external_rgb : (ctx->want_owned_rgb ? ctx->owned_rgb.ptr : nullptr));
@@ -399,7 +415,7 @@ int launch(rpt_ctx *ctx) {
     // variant 0 = default: the derived-layout per-pixel kernel in natural dispatch order with the per-tile object
     // masks of the prepass, 5 waves per SIMD (26) when the octree allows the derived layout, else the general kernel (1)
     int v = ctx->variant == 0 ? 26 : ctx->variant;
-    if (!ctx->compact_ok) v = 1;
+    if (!ctx->geo->compact_ok) v = 1;
     switch (v) {
     case 1: hipLaunchKernelGGL(rptd::rpt_render_kernel_v0, grid, dim3(256), 0, ctx->stream, a); break;
     case 2: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1, grid, dim3(256), 0, ctx->stream, a); break;
@@ -528,6 +544,8 @@ int rpt_create(rpt_ctx **out, int device_ordinal) {
     rpt_ctx *ctx = new (std::nothrow) rpt_ctx();
     if (!ctx) return RPT_ERR_NOMEM;
     ctx->device = device_ordinal;
+    ctx->geo = std::make_shared<Geometry>();
+    ctx->geo->device = device_ordinal;
     if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
 
         hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) {
@@ -545,8 +563,8 @@ void rpt_destroy(rpt_ctx *ctx) {
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->host_counts) (void)hipHostFree(ctx->host_counts);
     if (ctx->host_row_cost) (void)hipHostFree(ctx->host_row_cost);
-    for (DeviceBuffer *b : {&ctx->objects, &ctx->vertices, &ctx->normals, &ctx->uvs, &ctx->triangles, &ctx->octrees,
-                            &ctx->octreeTris, &ctx->textures, &ctx->dnodes, &ctx->dtris, &ctx->dobjs, &ctx->counters, &ctx->wave_times, &ctx->tile_masks, &ctx->bin_counts, &ctx->bin_lists, &ctx->row_cost, &ctx->owned_out, &ctx->owned_plane, &ctx->owned_rgb})
+    ctx->geo.reset();
+    for (DeviceBuffer *b : {&ctx->objects, &ctx->dobjs, &ctx->counters, &ctx->wave_times, &ctx->tile_masks, &ctx->bin_counts, &ctx->bin_lists, &ctx->row_cost, &ctx->owned_out, &ctx->owned_plane, &ctx->owned_rgb})
         release(*b);
     if (ctx->pinned_objects) (void)hipHostFree(ctx->pinned_objects);
     for (hipEvent_t e : ctx->staging_done) if (e) (void)hipEventDestroy(e);
@@ -570,29 +588,47 @@ int rpt_upload_scene(rpt_ctx *ctx, const rpt_scene_desc *s) {
     if (int rc = validate_geometry(ctx, *s)) return rc;
     RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->scene_uploaded = false;
-    if (int rc = upload(ctx, ctx->vertices, s->vertices, s->vertex_count * sizeof(rpt_float3))) return rc;
-    if (int rc = upload(ctx, ctx->normals, s->normals, s->normal_count * sizeof(rpt_float3))) return rc;
-    if (int rc = upload(ctx, ctx->uvs, s->uvs, s->uv_count * sizeof(rpt_float2))) return rc;
-    if (int rc = upload(ctx, ctx->triangles, s->triangles, s->triangle_words * sizeof(uint32_t))) return rc;
-    if (int rc = upload(ctx, ctx->octrees, s->octrees, s->octree_count * sizeof(rpt_octree))) return rc;
-    if (int rc = upload(ctx, ctx->octreeTris, s->octreeTris, s->octree_tri_count * sizeof(int32_t))) return rc;
-    if (int rc = upload(ctx, ctx->textures, s->textures, s->texture_bytes)) return rc;
-    ctx->vertex_count = s->vertex_count;
-    ctx->normal_count = s->normal_count;
-    ctx->uv_count = s->uv_count;
-    ctx->triangle_words = s->triangle_words;
-    ctx->octree_count = s->octree_count;
-    ctx->octree_tri_count = s->octree_tri_count;
+    // a fresh Geometry: contexts sharing the previous one (rpt_share_scene) keep it until they let go
+    ctx->geo = std::make_shared<Geometry>();
+    ctx->geo->device = ctx->device;
+    if (int rc = upload(ctx, ctx->geo->vertices, s->vertices, s->vertex_count * sizeof(rpt_float3))) return rc;
+    if (int rc = upload(ctx, ctx->geo->normals, s->normals, s->normal_count * sizeof(rpt_float3))) return rc;
+    if (int rc = upload(ctx, ctx->geo->uvs, s->uvs, s->uv_count * sizeof(rpt_float2))) return rc;
+    if (int rc = upload(ctx, ctx->geo->triangles, s->triangles, s->triangle_words * sizeof(uint32_t))) return rc;
+    if (int rc = upload(ctx, ctx->geo->octrees, s->octrees, s->octree_count * sizeof(rpt_octree))) return rc;
+    if (int rc = upload(ctx, ctx->geo->octreeTris, s->octreeTris, s->octree_tri_count * sizeof(int32_t))) return rc;
+    if (int rc = upload(ctx, ctx->geo->textures, s->textures, s->texture_bytes)) return rc;
+    ctx->geo->vertex_count = s->vertex_count;
+    ctx->geo->normal_count = s->normal_count;
+    ctx->geo->uv_count = s->uv_count;
+    ctx->geo->triangle_words = s->triangle_words;
+    ctx->geo->octree_count = s->octree_count;
+    ctx->geo->octree_tri_count = s->octree_tri_count;
     ctx->scene_epoch++;
     if (int rc = build_derived_geometry(ctx, *s)) return rc;
-    ctx->host_node_bounds.resize(s->octree_count * 6);
+    ctx->geo->host_node_bounds.resize(s->octree_count * 6);
     for (size_t i = 0; i < s->octree_count; i++) {
-        float *b = &ctx->host_node_bounds[6 * i];
+        float *b = &ctx->geo->host_node_bounds[6 * i];
         b[0] = s->octrees[i].min.x; b[1] = s->octrees[i].min.y; b[2] = s->octrees[i].min.z;
         b[3] = s->octrees[i].max.x; b[4] = s->octrees[i].max.y; b[5] = s->octrees[i].max.z;
     }
     ctx->scene_uploaded = true;
     const int rc = rpt_set_objects(ctx, s->objects, (int)s->object_count);
+    if (rc) ctx->scene_uploaded = false;
+    return rc;
+}
+
+int rpt_share_scene(rpt_ctx *ctx, rpt_ctx *owner) {
+    if (!ctx || !owner || ctx == owner) return RPT_ERR_ARG;
+    if (!owner->scene_uploaded) return fail(ctx, RPT_ERR_STATE, "rpt_share_scene: the owner has no scene");
+    if (ctx->device != owner->device) return fail(ctx, RPT_ERR_ARG, "rpt_share_scene: contexts are on different devices");
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->geo = owner->geo;
+    ctx->scene_epoch++;
+    ctx->scene_uploaded = true;
+    const int count = (int)(owner->host_objects.size() / sizeof(rpt_object));
+    const int rc = rpt_set_objects(ctx, count ? owner->host_objects.data() : nullptr, count);
     if (rc) ctx->scene_uploaded = false;
     return rc;
 }

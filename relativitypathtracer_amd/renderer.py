@@ -52,6 +52,10 @@ class Renderer:
         d = scene.desc()
         self._check(self._lib.rpt_upload_scene(self._h, C.byref(d)), "rpt_upload_scene")
 
+    def share_scene(self, owner: "Renderer"):
+        """Use the scene resident in `owner` (same device) instead of uploading a second copy: frames in flight."""
+        self._check(self._lib.rpt_share_scene(self._h, owner._h), "rpt_share_scene")
+
     def upload_desc(self, desc: _ffi.SceneDesc):
         self._check(self._lib.rpt_upload_scene(self._h, C.byref(desc)), "rpt_upload_scene")
 

@@ -56,3 +56,29 @@ def test_example_host_matches_oracle(tmp_path):
     opx, _, _ = oracle_ffi.render(s, W, H, want_rgb=False)
     want = opx["rgba"].reshape(H, W, 4)[::-1, :, :3]
     assert np.array_equal(img, want)
+
+
+@pytest.mark.gpu
+def test_example_host_frames_in_flight(tmp_path):
+    """40 frames with the clock running, 3 in flight over rpt_share_scene: the PPM holds the last frame."""
+    import oracle_ffi
+    from relativitypathtracer_amd import Scene
+    exe = build(tmp_path)
+    out = tmp_path / "anim.ppm"
+    W, H, frames = 320, 184, 40
+    with open(os.path.join(ASSETS, "Scenes", "shadows.txt")) as f:
+        p = subprocess.run([exe, str(W), str(H), str(out), "0", "0", "0", "16", str(frames), "3"], stdin=f, capture_output=True,
+                           text=True, env={**os.environ, "RPT_ASSETS": ASSETS})
+    assert p.returncode == 0, p.stderr
+    assert f"{frames} frames, 3 in flight" in p.stderr
+    data = out.read_bytes()
+    header = f"P6\n{W} {H}\n255\n".encode()
+    img = np.frombuffer(data[len(header):], np.uint8).reshape(H, W, 3)
+    s = Scene.from_file("shadows")
+    s.set_camera((0, 0, 0), 16.0)
+    s.set_paused(False)
+    for _ in range(frames):
+        s.advance_time(16)
+    s.update_objects()
+    opx, _, _ = oracle_ffi.render(s, W, H, want_rgb=False)
+    assert np.array_equal(img, opx["rgba"].reshape(H, W, 4)[::-1, :, :3])

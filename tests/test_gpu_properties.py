@@ -320,3 +320,56 @@ def test_animation_pipelined_frames(renderer):
         got = bufs[f].cpu().numpy().view(np.uint8).reshape(H * W, 16)[:, 8:12]
         opx, _, _ = oracle_ffi.render(scene, W, H, want_rgb=False, objects=snapshots[f])
         assert np.array_equal(got, opx["rgba"]), f"frame {f}"
+
+
+def test_frames_in_flight_share_one_scene():
+    """rpt_share_scene: three contexts, one resident scene, frames submitted round-robin without host waits and
+    overlapping on the device.  Every slot's frame must equal the oracle's render of the Object[] it was given;
+    the shared geometry must survive its first owner and a re-upload in another context."""
+    from relativitypathtracer_amd import Scene
+    from relativitypathtracer_amd.renderer import Renderer, RenderError
+    scene = Scene.from_file("shadows")
+    scene.set_paused(False)
+    scene.set_camera((0, 0, 0), 12.0)
+    scene.update_objects()
+    W, H = 480, 272
+    owner = Renderer(0)
+    with pytest.raises(RenderError):
+        Renderer(0).share_scene(owner)           # the owner has no scene yet
+    with pytest.raises(RenderError):
+        owner.share_scene(owner)
+    owner.upload_scene(scene)
+    slots = [owner, Renderer(0), Renderer(0)]
+    for r in slots[1:]:
+        r.share_scene(owner)
+    for r in slots:
+        r.set_scene_params(scene, W, H)
+        r.set_output(None)
+    snapshots = [None] * len(slots)
+    for f in range(31):                          # frame f in slot f mod 3; the last three frames are checked
+        scene.advance_time(250)
+        scene.update_objects()
+        k = f % len(slots)
+        slots[k].set_objects(scene)
+        slots[k].render_async()
+        snapshots[k] = scene.buffers()["objects"].copy()
+    for r in slots:
+        r.sync()
+    for k, r in enumerate(slots):
+        opx, _, _ = oracle_ffi.render(scene, W, H, want_rgb=False, objects=snapshots[k])
+        assert np.array_equal(r.read_framebuffer()["rgba"], opx["rgba"]), f"slot {k}"
+    assert not np.array_equal(slots[0].read_framebuffer()["rgba"], slots[1].read_framebuffer()["rgba"])
+
+    # the owner takes another scene, then goes away: the sharers still render the first one
+    other = load_config("cube")
+    owner.upload_scene(other)
+    owner.set_scene_params(other, W, H)
+    owner.render()
+    opx, _, _ = oracle_ffi.render(other, W, H, want_rgb=False)
+    assert np.array_equal(owner.read_framebuffer()["rgba"], opx["rgba"])
+    owner.close()
+    for k in (1, 2):
+        slots[k].render()
+        opx, _, _ = oracle_ffi.render(scene, W, H, want_rgb=False, objects=snapshots[k])
+        assert np.array_equal(slots[k].read_framebuffer()["rgba"], opx["rgba"]), f"slot {k} after the owner left"
+        slots[k].close()

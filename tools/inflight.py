@@ -35,7 +35,10 @@ def main():
     for _ in range(mmax):
         r = Renderer(0)
         r.set_variant(args.variant)
-        r.upload_scene(s)
+        if ctxs:
+            r.share_scene(ctxs[0])
+        else:
+            r.upload_scene(s)
         r.set_scene_params(s, args.width, args.height)
         ctxs.append(r)
     for world in [int(w) for w in args.world.split(",")]:
