@@ -10,11 +10,16 @@
  * stand-ins (its kernel is OpenCL C that the ROCm clang rejects for amdgcn —
  * opencl_kernel.cl:213 passes a __global pointer to a __private parameter — and
  * an x86 build would need an OpenCL built-in library the image lacks; its host
- * sources need <windows.h>, GLUT and GLEW).  The restatement below is therefore
- * pinned only (a) statistically, against the per-ray work counts the survey
- * recorded from the reference (see tests/test_oracle_stats.py),
- * and (b) visually, against the reference's own screenshots of static scenes
- * (tests/test_screenshots.py).  See DESIGN.md §3.
+ * sources need <windows.h>, GLUT and GLEW).  Which float rounding the author's
+ * GPU used is therefore unknown.  What the restatement below IS pinned by
+ * (tests/test_oracle.py) is the reference's own output:
+ * (a) its window grabs, reproduced at <= 1 LSB: the static scenes (arch1.png every
+ *     pixel, cube1.png) and the MOVING-camera grabs arch2.png (0.95c towards the
+ *     arch, light delay and shadows: all but 4 of 3.5 M pixels), cube2.png /
+ *     cube3.png (0.9c, without / with light propagation) at the camera states
+ *     recovered by tests/golden/fit_reference_camera.py;
+ * (b) the per-ray work counts the survey recorded from the reference
+ *     (SURVEY.md §8a).
  *
  * Every function follows one function of /root/reference/opencl_kernel.cl and
  * cites it.  Arithmetic is scalar IEEE-754 binary32, evaluated in exactly the

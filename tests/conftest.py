@@ -1,3 +1,4 @@
+import math
 import os
 import subprocess
 import sys
@@ -36,6 +37,29 @@ CONFIGS = {
     "ladder": dict(scene="ladder_paradox", v=(0.0, 0.0, 0.0), t=1.0),
     "soccer": dict(scene="soccer", v=(0.0, 0.0, 0.0), t=2.0),
 }
+
+
+# Camera states of the reference's own moving-frame screenshots (README.md:81-94), recovered by
+# tests/golden/fit_reference_camera.py: rapidity in steps of 1/5000 and clock in whole milliseconds are the only
+# states the reference's keyboard handling can reach (Render.cpp:159-177).
+REFERENCE_SHOTS = {
+    "cube1": dict(scene="cube", v=(0.0, 0.0, 0.0), t=0.0, interval=0),
+    "arch1": dict(scene="arch", v=(0.0, 0.0, 0.0), t=0.0, interval=-1),
+    "cube2": dict(scene="cube", v=(math.tanh(7373 / 5000.0), 0.0, 0.0), t=0.0, interval=0),
+    "cube3": dict(scene="cube", v=(math.tanh(7373 / 5000.0), 0.0, 0.0), t=4.174, interval=-1),
+    "arch2": dict(scene="arch", v=(0.0, 0.0, math.tanh(9209.8 / 5000.0)), t=5.761, interval=-1),
+}
+CLIENT_W, CLIENT_H = 2560, 1377      # client area of the reference's 2560x1400 window grabs
+
+
+def load_reference_shot(name):
+    from relativitypathtracer_amd import Scene
+    c = REFERENCE_SHOTS[name]
+    s = Scene.from_file(c["scene"])
+    s.set_camera(c["v"], c["t"])
+    s.set_interval(c["interval"])
+    s.update_objects()
+    return s
 
 
 def load_config(name):

@@ -2,14 +2,20 @@
 """Cuts test fixtures out of the reference's own output images (its README screenshots).
 
 Run in the build container only (needs /root/reference).  The fixtures are DATA the reference
-ships — window grabs of its own renderer — not source: `Screenshots/cube1.png` (Scenes/cube.txt,
-stationary camera) and `Screenshots/arch1.png` (Scenes/arch.txt, stationary camera).  Both scenes
-are static (every velocity 0), so the image does not depend on the unrecorded camera time and is
-reproducible from the scene file alone.  The 2560x1400 grabs carry a 23-row title bar; the client
-area is 2560x1377.
+ships — window grabs of its own renderer — not source.  The 2560x1400 grabs carry a 23-row title
+bar; the client area is 2560x1377.
 
-Written: an exact stride-4 subsample of each client area (every 4th pixel of every 4th row, no
-filtering) and one full-resolution 640x400 crop of arch1 around the arch, light and shadows.
+  cube1.png, arch1.png   Scenes/cube.txt, Scenes/arch.txt with the camera at rest.  Both scenes are static
+                         (every velocity 0), so the image does not depend on the unrecorded camera time
+                         and is reproducible from the scene file alone.
+  cube2.png, cube3.png   Scenes/cube.txt "moving frame (0.9c to the right)" without / with light propagation
+  arch2.png              Scenes/arch.txt "camera moving towards the arch at 0.95c" (README.md:81-94).
+                         The exact velocity and clock of these grabs are not recorded; they were recovered
+                         by tests/golden/fit_reference_camera.py (see there) and are kept in
+                         tests/conftest.py::REFERENCE_SHOTS.
+
+Written per image: an exact stride-4 subsample of the client area (every 4th pixel of every 4th row, no
+filtering) and one full-resolution crop of the part with the most detail.
 """
 import os
 import numpy as np
@@ -19,10 +25,20 @@ SRC = "/root/reference/Screenshots"
 DST = os.path.dirname(os.path.abspath(__file__))
 TITLE_BAR = 23
 
-for name in ("cube1", "arch1"):
+# name -> full-resolution crop (y0, y1, x0, x1) in client-area coordinates, or None
+CROPS = {
+    "cube1": None,
+    "arch1": (300, 700, 960, 1600),      # arch, light, shadows
+    "cube2": (826, 1377, 1150, 1410),    # the length-contracted crate
+    "cube3": (826, 1377, 1000, 1620),    # the crate as seen with light delay (Terrell rotation)
+    "arch2": (900, 1300, 960, 1600),     # brick floor under the arch: the most position-sensitive texture
+}
+
+for name, crop in CROPS.items():
     im = np.asarray(Image.open(os.path.join(SRC, name + ".png")).convert("RGB"))[TITLE_BAR:]
     assert im.shape == (1377, 2560, 3), im.shape
     Image.fromarray(np.ascontiguousarray(im[::4, ::4])).save(os.path.join(DST, f"ref_{name}_stride4.png"), optimize=True)
-    if name == "arch1":
-        Image.fromarray(np.ascontiguousarray(im[300:700, 960:1600])).save(os.path.join(DST, "ref_arch1_crop_y300_x960.png"), optimize=True)
+    if crop:
+        y0, y1, x0, x1 = crop
+        Image.fromarray(np.ascontiguousarray(im[y0:y1, x0:x1])).save(os.path.join(DST, f"ref_{name}_crop_y{y0}_x{x0}.png"), optimize=True)
 print("ok")

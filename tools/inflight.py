@@ -12,6 +12,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from relativitypathtracer_amd import Scene                      # noqa: E402
 from relativitypathtracer_amd.renderer import Renderer          # noqa: E402
 
@@ -27,7 +28,12 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-objects", action="store_true", help="do not refresh Object[] every frame (isolates the copy)")
     args = ap.parse_args()
-    s = Scene.from_file(args.scene)
+    import ablate
+    if ablate.SCENES.get(args.scene):               # the inline ablation scenes of tools/ablate.py (empty, sphere_light, ...)
+        s = Scene()
+        s.inputScene(ablate.SCENES[args.scene])
+    else:
+        s = Scene.from_file(args.scene)
     s.set_camera((0, 0, 0), 16.0 if args.scene == "shadows" else 0.0)
     s.update_objects()
     mmax = max(int(m) for m in args.inflight.split(","))
