@@ -49,6 +49,11 @@ REFERENCE_SHOTS = {
     "cube3": dict(scene="cube", v=(math.tanh(7373 / 5000.0), 0.0, 0.0), t=4.174, interval=-1),
     "arch2": dict(scene="arch", v=(0.0, 0.0, math.tanh(9209.8 / 5000.0)), t=5.761, interval=-1),
 }
+# Frames of the reference's animated GIFs (camera at rest, objects at 0.9c): (scene, frame index, camera clock)
+REFERENCE_GIF_FRAMES = {
+    "cubes": [("cubes", 26, 5.85)],                                                        # light propagation on
+    "ladder": [("ladder_paradox", 60, 2.42), ("ladder_paradox", 100, 3.98), ("ladder_paradox", 140, 5.56)],   # off
+}
 CLIENT_W, CLIENT_H = 2560, 1377      # client area of the reference's 2560x1400 window grabs
 
 

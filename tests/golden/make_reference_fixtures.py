@@ -14,6 +14,14 @@ bar; the client area is 2560x1377.
                          by tests/golden/fit_reference_camera.py (see there) and are kept in
                          tests/conftest.py::REFERENCE_SHOTS.
 
+  cubes.gif, ladder_paradox_garage_frame.gif
+                         800x429 palette animations of Scenes/cubes.txt (a line of cubes passing at 0.9c, light
+                         propagation on) and Scenes/ladder_paradox.txt (ruler and garage doors at 0.9c, light
+                         propagation off) from a camera at rest: single frames, converted to RGB as they are.  They
+                         pin the geometry of MOVING OBJECTS to the resolution of a rescaled palette image; their clock
+                         values (tests/conftest.py::REFERENCE_GIF_FRAMES) were found like the grabs' — and come out
+                         40 ms per frame apart for the ladder, the GIF's own frame time.
+
 Written per image: an exact stride-4 subsample of the client area (every 4th pixel of every 4th row, no
 filtering) and one full-resolution crop of the part with the most detail.
 """
@@ -41,4 +49,9 @@ for name, crop in CROPS.items():
     if crop:
         y0, y1, x0, x1 = crop
         Image.fromarray(np.ascontiguousarray(im[y0:y1, x0:x1])).save(os.path.join(DST, f"ref_{name}_crop_y{y0}_x{x0}.png"), optimize=True)
+for gif, frames in (("cubes", (26,)), ("ladder_paradox_garage_frame", (60, 100, 140))):
+    im = Image.open(os.path.join(SRC, gif + ".gif"))
+    for f in frames:
+        im.seek(f)
+        im.convert("RGB").save(os.path.join(DST, f"ref_{gif.split('_')[0]}_gif_frame{f}.png"), optimize=True)
 print("ok")

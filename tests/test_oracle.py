@@ -18,7 +18,7 @@ import pytest
 from PIL import Image
 
 import oracle_ffi
-from conftest import CLIENT_H, CLIENT_W, CONFIGS, REFERENCE_SHOTS, load_config, load_reference_shot
+from conftest import CLIENT_H, CLIENT_W, CONFIGS, REFERENCE_GIF_FRAMES, REFERENCE_SHOTS, load_config, load_reference_shot
 from relativitypathtracer_amd import Scene
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -94,6 +94,47 @@ def test_reference_screenshot_cube_moving_camera(shot, crop, fixture):
     if shot == "cube3":     # the pin is sharp: one millisecond of clock later a quarter of the crate is wrong
         off = _render_top_down(shot, rows=(y0, y1), dt=0.001)[:, x0:x1]
         assert (np.abs(off - ref_crop).max(axis=2) > 1).sum() > 20000
+
+
+def _render_gif_sized(scene, t):
+    """Oracle frame of a resting camera at clock t, box-filtered from the grab size down to the GIFs' 800x429."""
+    scene.set_camera((0, 0, 0), t)
+    scene.update_objects()
+    px, _, _ = oracle_ffi.render(scene, CLIENT_W, CLIENT_H, want_rgb=False)
+    img = px["rgba"].reshape(CLIENT_H, CLIENT_W, 4)[::-1, :, :3]
+    return np.asarray(Image.fromarray(np.ascontiguousarray(img)).resize((800, 429), Image.BOX)).astype(np.int16)
+
+
+def test_reference_gif_cubes_moving_objects_with_light_delay():
+    """Screenshots/cubes.gif, frame 26: a line of cubes passing a resting camera at 0.9c, seen with light delay
+    (object boosts + retarded positions), next to an identical line at rest.  Pinned to the resolution of a
+    rescaled 256-colour image: silhouettes overlap to 98 %, colours inside agree to the palette step."""
+    _, f, t = REFERENCE_GIF_FRAMES["cubes"][0]
+    ref = _load(f"ref_cubes_gif_frame{f}.png")
+    bg = np.array([47, 47, 76])
+    scene = Scene.from_file("cubes")
+
+    def compare(tt):
+        img = _render_gif_sized(scene, tt)
+        a, b = np.abs(img - bg).max(axis=2) > 12, np.abs(ref - bg).max(axis=2) > 12
+        return (a & b).sum() / (a | b).sum(), np.abs(img - ref)[a & b].mean()
+    iou, colour = compare(t)
+    assert iou > 0.975 and colour < 10.0, (iou, colour)
+    iou_off, _ = compare(t + 0.35)          # the moving line half a cube spacing further on
+    assert iou_off < 0.93, iou_off
+
+
+def test_reference_gif_ladder_paradox_moving_objects():
+    """Screenshots/ladder_paradox_garage_frame.gif: ruler and garage doors at 0.9c (x and y), light propagation
+    off.  Three frames 40 GIF frames apart fit camera clocks 1.56 s = 40 x 39 ms apart — the GIF's own 40 ms
+    frame time — and each matches visibly better there than 0.2 s earlier or later."""
+    scene = Scene.from_file("ladder_paradox")
+    crop = (slice(150, 270), slice(380, 700))        # the garage: everything that moves
+    for _, f, t in REFERENCE_GIF_FRAMES["ladder"]:
+        ref = _load(f"ref_ladder_gif_frame{f}.png")[crop]
+        err = {dt: np.abs(_render_gif_sized(scene, t + dt)[crop] - ref).mean() for dt in (-0.2, 0.0, 0.2)}
+        assert err[0.0] < 4.5, (f, err)
+        assert err[-0.2] > 1.15 * err[0.0] and err[0.2] > 1.15 * err[0.0], (f, err)
 
 
 # SURVEY.md §8(a) "Per-primary-ray work [probe, 1920x1080]" — measured from the reference itself
