@@ -257,7 +257,8 @@ def main():
                 "note": "submit, wait, submit ... like the reference's blocking runKernel(): the frame latency"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "rpt_render_kernel_v1_masked_w5 (+ rpt_tile_bin_kernel prepass)", "algorithmic_bytes_per_launch": alg,
+                         "kernel": "rpt_render_kernel_v1_masked_w5 (+ rpt_tile_bin_kernel prepass)" if args.variant == 0
+                                   else f"kernel variant {args.variant} (rpt_set_variant, include/rpt.h)", "algorithmic_bytes_per_launch": alg,
                          "launch_ms": round(kernel_ms, 4), "launches_overlapped": round(overlap, 3),
                          "definition": "achieved = algorithmic_bytes_per_launch / (launch_ms / launches_overlapped): launch_ms is the mean "
                                        "HIP-event duration of one launch on its own stream (what rocprofv3 reports per dispatch), "
