@@ -92,7 +92,14 @@ int rpt_set_stream(rpt_ctx *ctx, void *hip_stream);
 int rpt_set_debug_rgb(rpt_ctx *ctx, void *device_ptr_or_null_or_1);
 
 /* Kernel variant: 0 = default (fastest validated), others select alternative implementations of
- * the same path for A/B measurement; all produce identical results. */
+ * the same path for A/B measurement; all produce identical results.
+ *   0  default: 26, or 1 when the octree's children are not stored consecutively
+ *   1  reads the reference's Octree/triangle layouts only (any valid octree)
+ *   2, 3, 4   derived layouts, uncapped / 4 / 5 waves per SIMD, every object tested for every pixel
+ *   15, 16    + walk with neighbour prefetch and branch-free triangle pairs (uncapped / 4 waves)
+ *   25, 26, 27  per-tile object masks from the prepass, 4 / 5 / 6 waves per SIMD
+ *   28  masks + triangle-record prefetch;  31  masks + the pipelined walk
+ *   7, 8, 11  diagnostic builds (loop counters, primary rays only, per-wave timeline): not product paths */
 int rpt_set_variant(rpt_ctx *ctx, int variant);
 
 /* Render one frame and wait for it (the reference's runKernel + finish). */

@@ -59,16 +59,7 @@ struct rpt_ctx {
     DeviceBuffer objects;
     std::shared_ptr<Geometry> geo;                    // never null
     DeviceBuffer counters, wave_times;
-    DeviceBuffer row_cost;                            // per tile row: two alternating arrays of cycle counts
-    unsigned int *host_row_cost = nullptr;            // pinned read-back of an earlier frame's row costs
-    size_t host_row_cost_rows = 0;
-    long long row_cost_config = -1;
-    unsigned int row_parity = 0;
-    unsigned int *host_counts = nullptr;              // pinned read-back of the tile-class counters (grid-size estimate)
-    long long counts_config = -1;                     // configuration the read-back belongs to
-    unsigned int scene_epoch = 0;                     // bumped by rpt_upload_scene / rpt_set_params
-    unsigned int frame_parity = 0;
-    DeviceBuffer tile_masks, bin_counts, bin_lists;   // tile binning (variant 12)
+    DeviceBuffer tile_masks;                          // per-tile object masks of the prepass
     std::vector<uint8_t> host_objects;                // last Object[] (DObj depends on `interval`: rebuilt when it changes)
     DeviceBuffer dobjs;
     DeviceBuffer owned_out, owned_plane, owned_rgb;
@@ -381,37 +372,6 @@ int launch(rpt_ctx *ctx) {
     const int tiles = local_tile_count(ctx);
     if (tiles == 0) return RPT_OK;
     const dim3 grid((ctx->width + 31) / 32, tiles);
-    // dispatch-order hint (variant 17 only): dearest tile rows first
-    unsigned int *row_cost_dev = nullptr;
-    rptd::RowOrder order;
-    bool use_row_order = false;
-    if (ctx->variant == 17 && tiles <= 1024) {
-        const long long config = ((long long)ctx->scene_epoch << 40) | ((long long)tiles << 12) | (long long)(ctx->first_tile & 0xfff);
-        if ((size_t)tiles * 8 > ctx->row_cost.capacity || !ctx->host_row_cost || ctx->host_row_cost_rows < (size_t)tiles) {
-            RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (int rc = reserve(ctx, ctx->row_cost, (size_t)tiles * 8)) return rc;
-            if (ctx->host_row_cost) RPT_HIP(ctx, hipHostFree(ctx->host_row_cost));
-            RPT_HIP(ctx, hipHostMalloc((void **)&ctx->host_row_cost, (size_t)tiles * 4, hipHostMallocDefault));
-            ctx->host_row_cost_rows = (size_t)tiles;
-            ctx->row_cost_config = -1;
-        }
-        if (ctx->row_cost_config != config) {          // new configuration: forget what was measured
-            RPT_HIP(ctx, hipMemsetAsync(ctx->row_cost.ptr, 0, (size_t)tiles * 8, ctx->stream));
-            std::memset(ctx->host_row_cost, 0, (size_t)tiles * 4);
-            ctx->row_cost_config = config;
-        }
-        // order from the (possibly stale) read-back, dearest rows first; all zero -> natural order
-        unsigned int cmax = 0;
-        for (int r = 0; r < tiles; r++) cmax = ctx->host_row_cost[r] > cmax ? ctx->host_row_cost[r] : cmax;
-        use_row_order = cmax != 0;
-        std::vector<std::pair<unsigned int, int>> keyed((size_t)tiles);
-        for (int r = 0; r < tiles; r++) keyed[r] = {ctx->host_row_cost[r], r};
-        if (cmax != 0)
-            std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<unsigned int, int> &x, const std::pair<unsigned int, int> &y) { return x.first > y.first; });
-        for (int r = 0; r < tiles; r++) order.row[r] = (unsigned short)keyed[r].second;
-        row_cost_dev = (unsigned int *)ctx->row_cost.ptr + (size_t)tiles * (ctx->row_parity & 1);
-        a.row_cost = row_cost_dev;
-    }
     // variant 0 = default: the derived-layout per-pixel kernel in natural dispatch order with the per-tile object
     // masks of the prepass, 5 waves per SIMD (26) when the octree allows the derived layout, else the general kernel (1)
     int v = ctx->variant == 0 ? 26 : ctx->variant;
@@ -421,8 +381,6 @@ int launch(rpt_ctx *ctx) {
     case 2: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1, grid, dim3(256), 0, ctx->stream, a); break;
     case 3: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_w4, grid, dim3(256), 0, ctx->stream, a); break;
     case 4: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_w5, grid, dim3(256), 0, ctx->stream, a); break;
-    case 5: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_w6, grid, dim3(256), 0, ctx->stream, a); break;
-    case 6: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_w8, grid, dim3(256), 0, ctx->stream, a); break;
     case 7:
         if (int rc = reserve(ctx, ctx->counters, 16 * sizeof(unsigned long long))) return rc;
         RPT_HIP(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 16 * sizeof(unsigned long long), ctx->stream));
@@ -435,97 +393,31 @@ int launch(rpt_ctx *ctx) {
         a.wave_times = (unsigned long long *)ctx->wave_times.ptr;
         hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_timeline, grid, dim3(256), 0, ctx->stream, a);
         break;
-    case 12:
-    case 13: {
-        const int tiles_x = (ctx->width + 7) / 8;
-        const int n_tiles = tiles_x * tiles;
-        if (int rc = reserve(ctx, ctx->tile_masks, (size_t)n_tiles * 8)) return rc;
-        if (!ctx->bin_counts.ptr) {
-            if (int rc = reserve(ctx, ctx->bin_counts, 32)) return rc;            // two alternating sets of 4 counters
-            RPT_HIP(ctx, hipMemsetAsync(ctx->bin_counts.ptr, 0, 32, ctx->stream));
-            RPT_HIP(ctx, hipHostMalloc((void **)&ctx->host_counts, 16, hipHostMallocDefault));
-            std::memset(ctx->host_counts, 0xff, 16);                                // "unknown": first frames use the full grid
-        }
-        if (int rc = reserve(ctx, ctx->bin_lists, (size_t)n_tiles * 3 * 4)) return rc;
-        a.tiles_x = tiles_x;
-        a.n_tiles = n_tiles;
-        a.tile_masks = (unsigned long long *)ctx->tile_masks.ptr;
-        a.bin_counts = (unsigned int *)ctx->bin_counts.ptr + 4 * (ctx->frame_parity & 1);
-        a.bin_counts_next = (unsigned int *)ctx->bin_counts.ptr + 4 * ((ctx->frame_parity + 1) & 1);
-        ctx->frame_parity++;
-        a.bin_lists = (unsigned int *)ctx->bin_lists.ptr;
-        a.mesh_object_bits = 0;
-        for (int i = 0; i < ctx->object_count && i < 64; i++)
-            if (((const rpt_object *)ctx->host_objects.data())[i].type == RPT_MESH) a.mesh_object_bits |= 1ull << i;
-        // list length estimate: what an earlier frame of this configuration counted (read back without a
-        // sync, so it may be a frame or two old) plus a margin; the kernel strides, so any value is correct
-        unsigned int est = (unsigned int)n_tiles;
-        const unsigned int seen = ctx->host_counts[0] + ctx->host_counts[1];
-        const long long config = ((long long)ctx->scene_epoch << 40) | ((long long)n_tiles << 12) | (long long)(ctx->first_tile & 0xfff);
-        if (ctx->host_counts[0] != 0xffffffffu && ctx->counts_config == config && seen <= (unsigned int)n_tiles)
-            est = seen + seen / 2 + 256;     // generous: an overestimate costs a few idle blocks, an underestimate serialises
-        else
-            std::memset(ctx->host_counts, 0xff, 16);
-        if (est > (unsigned int)n_tiles) est = (unsigned int)n_tiles;
-        ctx->counts_config = config;
-        a.main_blocks = (int)((est + 3) / 4);
-        if (a.main_blocks < 1) a.main_blocks = 1;
-        const int strips = ((tiles_x + 7) / 8) * tiles;
-        hipLaunchKernelGGL(rptd::rpt_tile_bin_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, ctx->stream, a);
-        RPT_HIP(ctx, hipMemcpyAsync(ctx->host_counts, a.bin_counts, 16, hipMemcpyDeviceToHost, ctx->stream));
-        const dim3 bgrid(a.main_blocks + (strips + 3) / 4);
-        if (v == 12) hipLaunchKernelGGL(rptd::rpt_render_binned_v1, bgrid, dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(rptd::rpt_render_binned_v1_w4, bgrid, dim3(256), 0, ctx->stream, a);
-        break;
-    }
     case 15: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_pipe, grid, dim3(256), 0, ctx->stream, a); break;
     case 16: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_pipe_w4, grid, dim3(256), 0, ctx->stream, a); break;
-    case 17: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_ordered, grid, dim3(256), 0, ctx->stream, a, order); break;
-    case 18: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_packet, grid, dim3(256), 0, ctx->stream, a); break;
-    case 19: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_packet_w4, grid, dim3(256), 0, ctx->stream, a); break;
-    case 20: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_half, dim3(grid.x, grid.y * 2), dim3(256), 0, ctx->stream, a); break;
-    case 21: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_quarter, dim3((ctx->width + 15) / 16, grid.y * 2), dim3(256), 0, ctx->stream, a); break;
     case 25:
     case 26:
     case 27:
     case 28:
-    case 29:
-    case 30:
-    case 31: {   // natural order, per-tile object masks from the prepass (no lists)
+    case 31: {   // natural order, per-tile object masks from the prepass
         const int tiles_x = ((ctx->width + 31) / 32) * 4;          // tiles per row as the 32-pixel-wide blocks see them
         const int n_tiles = tiles_x * tiles;
         if (int rc = reserve(ctx, ctx->tile_masks, (size_t)n_tiles * 8)) return rc;
         a.tiles_x = tiles_x;
         a.n_tiles = n_tiles;
         a.tile_masks = (unsigned long long *)ctx->tile_masks.ptr;
-        a.bin_lists = nullptr;
-        a.bin_counts = nullptr;
-        a.mesh_object_bits = 0;
         hipLaunchKernelGGL(rptd::rpt_tile_bin_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, ctx->stream, a);
         if (v == 25) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked, grid, dim3(256), 0, ctx->stream, a);
         else if (v == 26) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_w5, grid, dim3(256), 0, ctx->stream, a);
         else if (v == 27) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_w6, grid, dim3(256), 0, ctx->stream, a);
-        else if (v == 30) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_pf_w5, grid, dim3(256), 0, ctx->stream, a);
         else if (v == 31) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_pipe_w4, grid, dim3(256), 0, ctx->stream, a);
-        else if (v == 28) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_pf, grid, dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_pf_w3, grid, dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_pf, grid, dim3(256), 0, ctx->stream, a);
         break;
     }
-    case 14: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_prio, grid, dim3(256), 0, ctx->stream, a); break;
     case 8: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only, grid, dim3(256), 0, ctx->stream, a); break;
-    case 9: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only_w6, grid, dim3(256), 0, ctx->stream, a); break;
-    case 10: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only_w8, grid, dim3(256), 0, ctx->stream, a); break;
     default: return fail(ctx, RPT_ERR_ARG, "unknown kernel variant");
     }
     RPT_HIP(ctx, hipGetLastError());
-    (void)use_row_order;
-    if (row_cost_dev && v == 17) {
-        // read this frame's row costs back without a sync (the host looks at them some frames later) and
-        // clear the other array for the next frame
-        RPT_HIP(ctx, hipMemcpyAsync(ctx->host_row_cost, row_cost_dev, (size_t)tiles * 4, hipMemcpyDeviceToHost, ctx->stream));
-        ctx->row_parity++;
-        RPT_HIP(ctx, hipMemsetAsync((unsigned int *)ctx->row_cost.ptr + (size_t)tiles * (ctx->row_parity & 1), 0, (size_t)tiles * 4, ctx->stream));
-    }
     return RPT_OK;
 }
 
@@ -561,10 +453,8 @@ void rpt_destroy(rpt_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
-    if (ctx->host_counts) (void)hipHostFree(ctx->host_counts);
-    if (ctx->host_row_cost) (void)hipHostFree(ctx->host_row_cost);
     ctx->geo.reset();
-    for (DeviceBuffer *b : {&ctx->objects, &ctx->dobjs, &ctx->counters, &ctx->wave_times, &ctx->tile_masks, &ctx->bin_counts, &ctx->bin_lists, &ctx->row_cost, &ctx->owned_out, &ctx->owned_plane, &ctx->owned_rgb})
+    for (DeviceBuffer *b : {&ctx->objects, &ctx->dobjs, &ctx->counters, &ctx->wave_times, &ctx->tile_masks, &ctx->owned_out, &ctx->owned_plane, &ctx->owned_rgb})
         release(*b);
     if (ctx->pinned_objects) (void)hipHostFree(ctx->pinned_objects);
     for (hipEvent_t e : ctx->staging_done) if (e) (void)hipEventDestroy(e);
@@ -604,7 +494,6 @@ int rpt_upload_scene(rpt_ctx *ctx, const rpt_scene_desc *s) {
     ctx->geo->triangle_words = s->triangle_words;
     ctx->geo->octree_count = s->octree_count;
     ctx->geo->octree_tri_count = s->octree_tri_count;
-    ctx->scene_epoch++;
     if (int rc = build_derived_geometry(ctx, *s)) return rc;
     ctx->geo->host_node_bounds.resize(s->octree_count * 6);
     for (size_t i = 0; i < s->octree_count; i++) {
@@ -625,7 +514,6 @@ int rpt_share_scene(rpt_ctx *ctx, rpt_ctx *owner) {
     RPT_HIP(ctx, hipSetDevice(ctx->device));
     RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->geo = owner->geo;
-    ctx->scene_epoch++;
     ctx->scene_uploaded = true;
     const int count = (int)(owner->host_objects.size() / sizeof(rpt_object));
     const int rc = rpt_set_objects(ctx, count ? owner->host_objects.data() : nullptr, count);
@@ -682,7 +570,6 @@ int rpt_set_params(rpt_ctx *ctx, const float white_point[3], float ambient, int 
     ctx->width = width;
     ctx->height = height;
     const bool interval_changed = ctx->interval != interval;
-    if (interval_changed || ctx->width != width || ctx->height != height) ctx->scene_epoch++;
     ctx->interval = interval;
     ctx->params_set = true;
     if (interval_changed && ctx->scene_uploaded && ctx->object_count > 0) {

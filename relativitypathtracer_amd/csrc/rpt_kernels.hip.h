@@ -83,21 +83,10 @@ struct KernelArgs {
     int width, height;
     int interval;
     int first_tile, tile_step;
-    // tile binning (variant 12): 8x8-pixel tiles of this context's rows, classified once per frame
+    // per-tile object masks: 8x8-pixel tiles of this context's rows, classified once per frame by rpt_tile_bin_kernel
     int tiles_x, n_tiles;                    // tiles per row, tiles in this context's rows
     unsigned long long *tile_masks;          // [n_tiles] bit i = primary rays of the tile may hit object i (i < 64)
-    unsigned int *bin_counts;                // [4] tiles with a mesh candidate / analytic candidates only / none
-    unsigned int *bin_counts_next;           // the other buffer of the pair, zeroed by the main kernel for the next frame
-    int main_blocks;                         // blocks of the binned kernel that walk the tile lists
-    // dispatch-order hint (any permutation is correct): tile row handled by blockIdx.y, dearest rows first, from
-    // the per-row cycle counts an earlier frame accumulated in row_cost (long octree-walk waves start at t = 0
-    // and the cheap rows fill the tail).  In the kernel-argument segment so it costs no dependent load.
-    unsigned int *row_cost;                  // [n local tile rows] accumulated wave cycles >> 10 (this frame)
-    unsigned int *bin_lists;                 // [3][n_tiles] tile ids per class
-    unsigned long long mesh_object_bits;     // which of the first 64 objects are meshes
 };
-
-struct RowOrder { unsigned short row[1024]; };   // second kernel argument of the row-ordered variant only
 
 struct Hit {                 // opencl_kernel.cl:38-44
     float dist;
@@ -349,8 +338,6 @@ RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &
     int closeSide, farSide;
     f3 nmin = node.bmin(a), nmax = node.bmax(a);
     if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
-    // waves that walk the octree are the frame's critical path: let them issue ahead of the cheap waves
-    if (V == 5) __builtin_amdgcn_s_setprio(3);
     f3 uv = newRay.origin + newRay.dir * d.x;
 
     if (d.x < 0) {   // ray starts inside the root: descend to the leaf holding the origin
@@ -362,10 +349,7 @@ RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &
         }
         nmin = node.bmin(a);
         nmax = node.bmax(a);
-        if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) {
-            if (V == 5) __builtin_amdgcn_s_setprio(0);
-            return false;
-        }
+        if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
         uv = newRay.origin + newRay.dir * d.x;
     }
 
@@ -465,7 +449,6 @@ RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &
         diag_add<V>(5, 1);
         if (stop) break;
     }
-    if (V == 5) __builtin_amdgcn_s_setprio(0);
     if (V == 2) {   // diagnostic: longest single walk (leaf steps) and a coarse histogram of walk lengths
         atomicMax(&a.counters[6], (unsigned long long)steps);
         if (steps > 32) atomicAdd(&a.counters[7], 1ull);
@@ -600,184 +583,6 @@ RPT_DEV bool octree_core_pipelined(const KernelArgs &a, const rpt_object &obj, c
     return true;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Packet walk.  Rays of one 8x8 tile are coherent: at 4K the active lanes of a wave stand in 2.4 different
-// octree nodes on average per step, and in a single node 42 % of the time (tools/divergence.py).  So the
-// walk is organised by NODE VISIT instead of by ray: each round picks the node of the first active lane;
-// if at least a quarter of the active lanes stand in that node, its 64-B record and its triangle records
-// are read ONCE through the scalar cache (SGPR operands, no per-lane loads, no max-over-lanes triangle
-// count) and all those lanes take the visit together; otherwise every active lane takes one visit of its
-// own node with vector loads.  Per ray the sequence of visits and every arithmetic operation are those of
-// octree_core (opencl_kernel.cl:200-308): only the scheduling differs.
-struct NodeData { f3 nmin, nmax; int firstChild, leafBegin, leafCount; int nb0, nb1, nb2, nb3, nb4, nb5; };
-
-struct WalkState {
-    f3 uv;
-    ExitPlan plan;
-    int idx;
-    int steps;
-    int hitTri;
-    bool active;     // still walking
-    bool arrive;     // uv is in object coordinates and must be normalised by the node it arrives at
-    bool pre;        // ray started inside the root: descending to the leaf that holds the origin
-    bool didHit;
-};
-
-RPT_DEV int pick_neighbor(const NodeData n, int side) {
-    int r = n.nb0;
-    r = side == 1 ? n.nb1 : r;
-    r = side == 2 ? n.nb2 : r;
-    r = side == 3 ? n.nb3 : r;
-    r = side == 4 ? n.nb4 : r;
-    r = side == 5 ? n.nb5 : r;
-    return r;
-}
-
-// One visit of node `n` by the calling lanes.  SCALAR: the triangle records are read with a wave-uniform
-// index (one scalar-cache read per record for the whole group); otherwise per lane.
-template <bool SCALAR>
-RPT_DEV void visit_node(const KernelArgs &a, const NodeData n, const Ray &ray, WalkState &st, Hit &hit) {
-    if (st.arrive) st.uv = (st.uv - n.nmin) / (n.nmax - n.nmin);
-    if (n.firstChild != -1) {
-        st.idx = n.firstChild + octree_child_step_fast(st.uv);
-        st.arrive = false;
-        return;
-    }
-    if (st.pre) {   // the leaf that holds the origin: the walk proper starts from its entry point (opencl_kernel.cl:242-251)
-        f2 d;
-        int cs, fs;
-        if (!intersect_AABB(n.nmin, n.nmax, ray, d, cs, fs)) {
-            st.active = false;
-            return;
-        }
-        st.uv = ray.origin + ray.dir * d.x;
-        st.plan = makeExitPlan(normalize(ray.dir / (n.nmax - n.nmin)));
-        st.pre = false;
-        st.arrive = true;      // same node again: next visit normalises uv and handles it as a leaf
-        return;
-    }
-    if (++st.steps > RPT_MAX_LEAF_STEPS) {
-        st.active = false;
-        return;
-    }
-    const int kend = n.leafBegin + n.leafCount;
-    for (int k = n.leafBegin; k < kend; k++) {
-        f3 A, v0v1, v0v2;
-        int tri;
-        if (SCALAR) {
-            const DTri &t = a.dtris[k];
-            A = mk3(t.ax, t.ay, t.az);
-            v0v1 = mk3(t.e1x, t.e1y, t.e1z);
-            v0v2 = mk3(t.e2x, t.e2y, t.e2z);
-            tri = t.tri;
-        } else {
-            const DTriRec t = load_dtri(a, k);
-            A = t.A; v0v1 = t.v0v1; v0v2 = t.v0v2; tri = t.id;
-        }
-        float dist;
-        f2 triUV;
-        if (intersect_triangle_edges(A, v0v1, v0v2, ray, dist, triUV)) {
-            if (0 <= dist && dist < hit.dist) {
-                st.hitTri = tri;
-                hit.dist = dist;
-                hit.uv = triUV;
-                st.didHit = true;
-            }
-        }
-    }
-    const f3 extents = n.nmax - n.nmin;
-    const int farSide = getOppositeBoxSide(st.plan, st.uv);
-    st.uv = n.nmin + st.uv * extents;
-    st.idx = pick_neighbor(n, farSide);
-    st.arrive = true;
-    if (length(st.uv - ray.origin) > hit.dist) st.active = false;
-    if (st.idx == -1) st.active = false;
-}
-
-RPT_DEV NodeData node_from_record(const DNode &r) {
-    NodeData n;
-    n.nmin = mk3(r.minx, r.miny, r.minz);
-    n.nmax = mk3(r.maxx, r.maxy, r.maxz);
-    n.firstChild = r.firstChild;
-    n.leafBegin = r.leafBegin;
-    n.leafCount = r.leafCount;
-    n.nb0 = r.nb[0]; n.nb1 = r.nb[1]; n.nb2 = r.nb[2]; n.nb3 = r.nb[3]; n.nb4 = r.nb[4]; n.nb5 = r.nb[5];
-    return n;
-}
-
-RPT_DEV NodeData node_from_vector_load(const KernelArgs &a, int idx) {
-    NodeRef<1> r;
-    r.load(a, idx);
-    NodeData n;
-    n.nmin = r.bmin(a);
-    n.nmax = r.bmax(a);
-    n.firstChild = r.first_child();
-    n.leafBegin = r.tri_begin(a);
-    n.leafCount = r.tri_count(a);
-    n.nb0 = r.q2.y; n.nb1 = r.q2.z; n.nb2 = r.q2.w; n.nb3 = r.q3.x; n.nb4 = r.q3.y; n.nb5 = r.q3.z;
-    return n;
-}
-
-RPT_DEV bool octree_core_packet(const KernelArgs &a, const rpt_object &obj, const Ray &newRay, f3 world_origin,
-                                float world_dirlen, Hit &hit) {
-    WalkState st;
-    st.idx = obj.meshIndex;
-    st.steps = 0;
-    st.hitTri = 0;
-    st.didHit = false;
-    st.arrive = true;
-    st.pre = false;
-    {
-        const NodeData root = node_from_record(a.dnodes[obj.meshIndex]);     // wave-uniform index
-        f2 d;
-        int closeSide, farSide;
-        st.active = intersect_AABB(root.nmin, root.nmax, newRay, d, closeSide, farSide);
-        st.uv = newRay.origin + newRay.dir * d.x;
-        st.plan = makeExitPlan(normalize(newRay.dir / (root.nmax - root.nmin)));
-        if (st.active && d.x < 0) {     // origin inside the root: find its leaf first (uv relative to the root, no renormalisation)
-            st.uv = (newRay.origin - root.nmin) / (root.nmax - root.nmin);
-            st.pre = true;
-            st.arrive = false;
-        }
-    }
-    const bool entered = st.active;
-    while (true) {
-        const unsigned long long act = __ballot(st.active);
-        if (!act) break;
-        const int leader = __ffsll((long long)act) - 1;
-        const int n0 = __builtin_amdgcn_readlane(st.idx, leader);
-        const bool member = st.active && st.idx == n0;
-        const unsigned long long mem = __ballot(member);
-        if (4 * __popcll(mem) >= __popcll(act)) {
-            if (member) {
-                const NodeData n = node_from_record(a.dnodes[n0]);          // scalar-cache read, shared by the group
-                visit_node<true>(a, n, newRay, st, hit);
-            }
-        } else if (st.active) {
-            const NodeData n = node_from_vector_load(a, st.idx);
-            visit_node<false>(a, n, newRay, st, hit);
-        }
-    }
-    if (!entered || !st.didHit) return false;
-
-    const int hitTri = st.hitTri;
-    const float u = hit.uv.x, v = hit.uv.y;
-    const float w = 1.0f - u - v;
-    const f3 normA = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 0]]);
-    const f3 normB = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 1]]);
-    const f3 normC = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 2]]);
-    hit.normal = normalize(applyTranspose(obj.InvM, normA * w + normB * u + normC * v));
-    const rpt_float2 uvA = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 0]];
-    const rpt_float2 uvB = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 1]];
-    const rpt_float2 uvC = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 2]];
-    hit.uv.x = w * uvA.x + u * uvB.x + v * uvC.x;
-    hit.uv.y = w * uvA.y + u * uvB.y + v * uvC.y;
-    const f3 objPoint = newRay.origin + newRay.dir * hit.dist;
-    const f3 worldPoint = transformPoint(obj.M, objPoint);
-    hit.dist = length(worldPoint - world_origin) / world_dirlen;
-    return true;
-}
-
 RPT_DEV float max3(f3 v) { return cl_max(cl_max(v.x, v.y), v.z); }   // opencl_kernel.cl:310
 RPT_DEV float cube_winding(f3 origin) {
     return max3(mk3(__builtin_fabsf(origin.x), __builtin_fabsf(origin.y), __builtin_fabsf(origin.z))) < 1.0f ? -1.0f : 1.0f;
@@ -851,7 +656,6 @@ RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, H
         newRay.origin = origin;
         newRay.dir = dir;
         if (V == 6 || V == 12) return octree_core_pipelined(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
-        if (V == 8) return octree_core_packet(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
         return octree_core<V>(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
     }
     default:
@@ -882,7 +686,6 @@ RPT_DEV bool intersect_object_primary(const KernelArgs &a, int i, f4 rayDir, Hit
         newRay.dir = dir;
         const f3 cam3 = mk3(obj.stationaryCam.y, obj.stationaryCam.z, obj.stationaryCam.w);
         if (V == 6 || V == 12) return octree_core_pipelined(a, obj, newRay, cam3, length(d3), hit);
-        if (V == 8) return octree_core_packet(a, obj, newRay, cam3, length(d3), hit);
         return octree_core<V>(a, obj, newRay, cam3, length(d3), hit);
     }
     default:
@@ -1050,27 +853,21 @@ RPT_DEV uint32_t tonemap_pack(const KernelArgs &a, f3 color, f3 &mapped) {
 // One thread per pixel, wave = 8x8 tile, workgroup = 32x8 strip.
 //   V = 0: reads the reference layouts only (general fallback, any valid octree)
 //   V = 1: derived DNode/DTri/DObj layouts
-// S = 0: a wave owns 8x8 pixels (all 64 lanes); S = 1: 8x4 pixels on 32 lanes; S = 2: 4x4 pixels on 16 lanes.
-// Under-filled waves trade throughput for latency: a wave's walk lasts as long as its slowest lane, so
-// fewer lanes per wave shorten the frame's critical path when there are too few pixels to fill the chip
-// (small frames, or one rank's share of a frame split over several GPUs).
-template <int V, int S = 0>
-RPT_DEV void render_pixel_body(const KernelArgs &a, const RowOrder *order = nullptr) {
+//   V = 2, 3, 4: diagnostic builds (loop counters, primary rays only, per-wave timeline); V = 6: pipelined walk
+//   V = 10: per-tile object masks from the prepass (the default); 11: + triangle-record prefetch; 12: + pipelined walk
+template <int V>
+RPT_DEV void render_pixel_body(const KernelArgs &a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    if (S > 0 && lane >= (64 >> S)) return;
     unsigned long long t_start = 0;
     if (V == 4) {
         t_start = wall_clock64();
         if ((threadIdx.x & 63) < 8) rpt_diag_lds[threadIdx.x >> 6][threadIdx.x & 63] = 0;
         rpt_diag_lds[threadIdx.x >> 6][6] = clock64();
     }
-    const unsigned long long c_start = (V == 7 && a.row_cost) ? (unsigned long long)clock64() : 0ull;
-    // blockIdx.y counts bands of (8 >> (S ? 1 : 0)) rows inside the 8-row tiles of this context
-    const int band = (int)blockIdx.y;
-    const int tile_row = (V == 7 && order) ? (int)order->row[band] : (S ? band >> 1 : band);
-    const int row_in_tile = S ? ((band & 1) * 4 + (S == 1 ? (lane >> 3) : (lane >> 2))) : (lane >> 3);
-    const int x_coord = S == 2 ? ((int)blockIdx.x * 16 + wave * 4 + (lane & 3)) : ((int)blockIdx.x * 32 + wave * 8 + (lane & 7));
+    const int tile_row = (int)blockIdx.y;        // 8-row tiles of this context, natural order
+    const int row_in_tile = lane >> 3;
+    const int x_coord = (int)blockIdx.x * 32 + wave * 8 + (lane & 7);
     const int local_row = tile_row * RPT_TILE_ROWS + row_in_tile;
     const int y_coord = (a.first_tile + tile_row * a.tile_step) * RPT_TILE_ROWS + row_in_tile;
     if (x_coord >= a.width || y_coord >= a.height) return;   // the reference has no guard (UB)
@@ -1079,7 +876,7 @@ RPT_DEV void render_pixel_body(const KernelArgs &a, const RowOrder *order = null
     f3 mapped = mk3(a.bg_mapped[0], a.bg_mapped[1], a.bg_mapped[2]);
     uint32_t packed = a.bg_packed;
     unsigned long long object_mask = ~0ull;
-    if (V == 10 || V == 11 || V == 12) {   // per-tile object mask of the binning prepass, natural dispatch order
+    if (V == 10 || V == 11 || V == 12) {   // per-tile object mask of the prepass
         const int tile = __builtin_amdgcn_readfirstlane(tile_row * a.tiles_x + (int)blockIdx.x * 4 + wave);
         object_mask = a.tile_masks[tile];
     }
@@ -1103,11 +900,6 @@ RPT_DEV void render_pixel_body(const KernelArgs &a, const RowOrder *order = null
         a.debug_rgb[3 * id + 1] = mapped.y;
         a.debug_rgb[3 * id + 2] = mapped.z;
     }
-    if (V == 7 && a.row_cost) {   // feed the next frames' dispatch order: only waves that were expensive report
-        const unsigned long long cyc = (unsigned long long)clock64() - c_start;
-        const unsigned long long m = __ballot(1);
-        if (cyc > 16384ull && lane == __ffsll((long long)m) - 1) atomicAdd(&a.row_cost[tile_row], (unsigned int)(cyc >> 10));
-    }
     if (V == 4 && a.wave_times) {
         const unsigned long long t_end = wall_clock64();
         const unsigned long long m = __ballot(1);
@@ -1125,28 +917,16 @@ __global__ __launch_bounds__(256) void rpt_render_kernel_v0(const KernelArgs a) 
 __global__ __launch_bounds__(256) void rpt_render_kernel_v1(const KernelArgs a) { render_pixel_body<1>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_w4(const KernelArgs a) { render_pixel_body<1>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_v1_w5(const KernelArgs a) { render_pixel_body<1>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_v1_w6(const KernelArgs a) { render_pixel_body<1>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_v1_w8(const KernelArgs a) { render_pixel_body<1>(a); }
 __global__ __launch_bounds__(256) void rpt_render_kernel_v1_diag(const KernelArgs a) { render_pixel_body<2>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_timeline(const KernelArgs a) { render_pixel_body<4>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_prio(const KernelArgs a) { render_pixel_body<5>(a); }
 __global__ __launch_bounds__(256) void rpt_render_kernel_v1_pipe(const KernelArgs a) { render_pixel_body<6>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_pipe_w4(const KernelArgs a) { render_pixel_body<6>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_ordered(const KernelArgs a, const RowOrder o) { render_pixel_body<7>(a, &o); }
-__global__ __launch_bounds__(256) void rpt_render_kernel_v1_packet(const KernelArgs a) { render_pixel_body<8>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_packet_w4(const KernelArgs a) { render_pixel_body<8>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_half(const KernelArgs a) { render_pixel_body<1, 1>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_quarter(const KernelArgs a) { render_pixel_body<1, 2>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_masked(const KernelArgs a) { render_pixel_body<10>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_masked_pf(const KernelArgs a) { render_pixel_body<11>(a); }
-__global__ __launch_bounds__(256) void rpt_render_kernel_v1_masked_pf_w3(const KernelArgs a) { render_pixel_body<11>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_v1_masked_w5(const KernelArgs a) { render_pixel_body<10>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_v1_masked_w6(const KernelArgs a) { render_pixel_body<10>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_v1_masked_pf_w5(const KernelArgs a) { render_pixel_body<11>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_masked_pipe_w4(const KernelArgs a) { render_pixel_body<12>(a); }
 __global__ __launch_bounds__(256) void rpt_render_kernel_primary_only(const KernelArgs a) { render_pixel_body<3>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_primary_only_w6(const KernelArgs a) { render_pixel_body<3>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_primary_only_w8(const KernelArgs a) { render_pixel_body<3>(a); }
 
 // ---------------------------------------------------------------------------------------------
 // Tile binning prepass (one thread per 8x8 tile).  For every object it asks whether ANY primary ray
@@ -1215,112 +995,7 @@ __global__ __launch_bounds__(256) void rpt_tile_bin_kernel(const KernelArgs a) {
         if (a.object_count > 64) mask |= 0ull;   // objects >= 64 are never culled (trace() tests them always)
         a.tile_masks[tile] = mask;
     }
-    if (!a.bin_lists) return;      // masks only (the per-pixel kernel in natural order reads them)
-    // class 0: a mesh may be hit (octree walk: the long waves, scheduled first); 1: analytic objects only;
-    // 2: nothing (background fill).  With more than 64 objects every tile is at least class 1.
-    int cls = 2;
-    if (mask & a.mesh_object_bits) cls = 0;
-    else if (mask || a.object_count > 64) cls = 1;
-    for (int c = 0; c < 3; c++) {           // wave-aggregated append
-        const unsigned long long m = __ballot(valid && cls == c);
-        if (m) {
-            const int lane = threadIdx.x & 63;
-            unsigned int base = 0;
-            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&a.bin_counts[c], (unsigned int)__popcll(m));
-            base = __shfl(base, __ffsll((long long)m) - 1);
-            if (valid && cls == c) a.bin_lists[(size_t)c * a.n_tiles + base + __popcll(m & ((1ull << lane) - 1))] = (unsigned int)tile;
-        }
-    }
 }
-
-// Binned main kernel, one launch: blocks [0, main_blocks) render the NON-EMPTY tiles, one wave per tile,
-// taken from the class lists in the order mesh -> analytic, so the long octree-walk waves are dispatched
-// first and the cheap ones fill the tail; main_blocks is the host's estimate of the list length (last
-// frame's count plus a margin) and the waves stride over the lists, so any estimate is correct.  Blocks
-// [main_blocks, gridDim.x) write the background of the empty tiles: one wave owns a 64x8 strip = 8
-// consecutive tiles of a tile row, reads their masks and streams the empty ones out (no per-pixel math).
-template <int V>
-RPT_DEV void render_one_tile(const KernelArgs &a, int tile, int lane) {
-    const unsigned long long mask = a.tile_masks[tile];
-    const int tx = tile % a.tiles_x, trow = tile / a.tiles_x;
-    const int x_coord = tx * 8 + (lane & 7);
-    const int local_row = trow * RPT_TILE_ROWS + (lane >> 3);
-    const int y_coord = (a.first_tile + trow * a.tile_step) * RPT_TILE_ROWS + (lane >> 3);
-    if (x_coord >= a.width || y_coord >= a.height) return;
-    f3 mapped = mk3(a.bg_mapped[0], a.bg_mapped[1], a.bg_mapped[2]);
-    uint32_t packed = a.bg_packed;
-    const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);
-    f3 color;
-    if (trace<V>(a, camdir, mask, color)) packed = tonemap_pack(a, color, mapped);
-    const size_t id = (size_t)y_coord * a.width + x_coord;
-    if (a.out16) {
-        uint4 px;
-        px.x = __float_as_uint((float)x_coord);
-        px.y = __float_as_uint((float)y_coord);
-        px.z = packed;
-        px.w = 0u;
-        reinterpret_cast<uint4 *>(a.out16)[id] = px;
-    }
-    if (a.plane) a.plane[(size_t)local_row * a.width + x_coord] = packed;
-    if (a.debug_rgb) {
-        a.debug_rgb[3 * id + 0] = mapped.x;
-        a.debug_rgb[3 * id + 1] = mapped.y;
-        a.debug_rgb[3 * id + 2] = mapped.z;
-    }
-}
-
-RPT_DEV void fill_strip(const KernelArgs &a, int strip, int lane) {
-    const int strips_x = (a.tiles_x + 7) / 8;
-    const int n_rows = a.n_tiles / a.tiles_x;
-    if (strip >= strips_x * n_rows) return;
-    const int trow = strip / strips_x, tx0 = (strip % strips_x) * 8;
-    const int y_coord = (a.first_tile + trow * a.tile_step) * RPT_TILE_ROWS + (lane >> 3);
-    const int local_row = trow * RPT_TILE_ROWS + (lane >> 3);
-    const bool many = a.object_count > 64;      // objects beyond the mask are always tested: no tile is "empty"
-    for (int t = 0; t < 8; t++) {
-        const int tx = tx0 + t;
-        if (tx >= a.tiles_x) break;
-        const unsigned long long mask = a.tile_masks[trow * a.tiles_x + tx];
-        if (mask != 0 || many) continue;
-        const int x_coord = tx * 8 + (lane & 7);
-        if (x_coord >= a.width || y_coord >= a.height) continue;
-        const size_t id = (size_t)y_coord * a.width + x_coord;
-        if (a.out16) {
-            uint4 px;
-            px.x = __float_as_uint((float)x_coord);
-            px.y = __float_as_uint((float)y_coord);
-            px.z = a.bg_packed;
-            px.w = 0u;
-            reinterpret_cast<uint4 *>(a.out16)[id] = px;
-        }
-        if (a.plane) a.plane[(size_t)local_row * a.width + x_coord] = a.bg_packed;
-        if (a.debug_rgb) {
-            a.debug_rgb[3 * id + 0] = a.bg_mapped[0];
-            a.debug_rgb[3 * id + 1] = a.bg_mapped[1];
-            a.debug_rgb[3 * id + 2] = a.bg_mapped[2];
-        }
-    }
-}
-
-template <int V>
-RPT_DEV void render_binned_body(const KernelArgs &a) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    if ((int)blockIdx.x >= a.main_blocks) {
-        fill_strip(a, __builtin_amdgcn_readfirstlane(((int)blockIdx.x - a.main_blocks) * 4 + wave), lane);
-        return;
-    }
-    if (blockIdx.x == 0 && threadIdx.x < 4) a.bin_counts_next[threadIdx.x] = 0;   // counters of the next frame
-    const unsigned int c0 = a.bin_counts[0], c1 = a.bin_counts[1];
-    const unsigned int stride = (unsigned int)a.main_blocks * 4u;
-    for (unsigned int g = (unsigned int)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave)); g < c0 + c1; g += stride) {
-        const unsigned int slot = g < c0 ? g : (unsigned int)a.n_tiles + (g - c0);
-        render_one_tile<V>(a, __builtin_amdgcn_readfirstlane((int)a.bin_lists[slot]), lane);
-    }
-}
-
-__global__ __launch_bounds__(256) void rpt_render_binned_v1(const KernelArgs a) { render_binned_body<1>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_binned_v1_w4(const KernelArgs a) { render_binned_body<1>(a); }
 
 // Root-side reassembly after the gather: plane of rank r, local tile k -> global tile r + k*n_ranks.
 __global__ __launch_bounds__(256) void rpt_scatter_plane_kernel(const uint32_t *planes, rpt_pixel *out16, int width,

@@ -276,7 +276,7 @@ def test_more_than_64_objects(renderer):
     scene.update_objects()
     W, H = 400, 224
     opx, orgb, _ = oracle_ffi.render(scene, W, H)
-    for variant in (0, 3, 13, 1):
+    for variant in (0, 3, 31, 1):
         _setup(renderer, scene, W, H, variant)
         renderer.set_debug_rgb(True)
         renderer.render()
