@@ -144,8 +144,9 @@ int rpt_scatter_colour_plane_on(rpt_ctx *ctx, void *hip_stream, const void *plan
  * [10..15] histogram of distinct nodes per step (1, 2, 3-4, 5-8, 9-16, >16). */
 int rpt_read_counters(rpt_ctx *ctx, unsigned long long out[16]);
 
-/* Diagnostic variant 7 only: per-wavefront {start, end} stamps (100 MHz s_memrealtime) of the last
- * frame, wave w = (blockIdx.y*gridDim.x + blockIdx.x)*4 + wave-in-block. */
+/* Diagnostic variant 11 only: ten words per wavefront of the last frame — {start, end} stamps (100 MHz
+ * s_memrealtime) and the cycle / iteration accounting of the walk's loops (tools/timeline.py);
+ * wave w = (blockIdx.y*gridDim.x + blockIdx.x)*4 + wave-in-block. */
 int rpt_read_wave_times(rpt_ctx *ctx, unsigned long long *out, size_t max_words, size_t *words);
 
 /* GPU octree build (replaces Mesh::GenerateOctree, Mesh.cpp:5-28, and Subdivide, Octree.cpp:171-248): builds the

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-wavefront timeline of one frame (diagnostic kernel variant 7): where is the critical path?"""
+"""Per-wavefront timeline of one frame (diagnostic kernel variant 11): where is the critical path?"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
