@@ -216,6 +216,7 @@ def main():
         r._check(r._lib.rpt_timing_end(r._h, C.byref(tot), C.byref(nfr)), "rpt_timing_end")
         blocking_kernel_ms = tot.value / max(nfr.value, 1)
         frame.last = frame.slots[0]
+        frame.slots[0].frames += nb
 
     if n > 1:
         tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
@@ -286,7 +287,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_ffi
             # every framebuffer that received frames: the root's, or (no exchange) the one of each slot in flight
-            fbs = [frame.framebuffer] if frame.exchange else [sl.framebuffer for sl in frame.slots]
+            fbs = [frame.framebuffer] if frame.exchange else [sl.framebuffer for sl in frame.slots if sl.frames]
             fbs = [f.cpu().numpy().view(np.uint8).reshape(H, W, 16) for f in fbs]
             ok = True
             for (r0, r1) in [(0, 8), (H * 2 // 5, H * 2 // 5 + 16), (H // 2, H // 2 + 16), (H - 8, H)]:

@@ -73,7 +73,7 @@ def reassemble_planes(planes: np.ndarray, width: int, height: int, world: int) -
 
 class _Slot:
     """One frame in flight: a context (rpt_ctx) on its own stream with its own output buffers."""
-    __slots__ = ("r", "stream", "framebuffer", "plane", "gathered", "work", "scattered")
+    __slots__ = ("r", "stream", "framebuffer", "plane", "gathered", "work", "scattered", "frames")
 
 
 class FrameSharder:
@@ -117,6 +117,7 @@ class FrameSharder:
             s.stream = torch.cuda.Stream(device=dev)
             r.set_stream(s.stream.cuda_stream)
             s.framebuffer = s.plane = s.gathered = s.work = s.scattered = None
+            s.frames = 0                         # frames submitted to this slot
             if not self.exchange:
                 r.set_rows(0, 1, False)
                 s.framebuffer = torch.zeros(width * height * 4, dtype=torch.int32, device=dev)
@@ -147,6 +148,7 @@ class FrameSharder:
         import torch
         slot = self.slots[self.frame % self.depth]
         self.frame += 1
+        slot.frames += 1
         self.last = slot
         if not self.exchange:                 # the context launches on the slot's stream itself: no torch state to switch
             if objects is not None:
