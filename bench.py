@@ -78,6 +78,7 @@ def cpu_baseline(scene, width, height, budget_s=12.0):
     t1 = time.perf_counter()
     oracle_ffi.render(scene, width, height, rows=band, want_rgb=False, threads=1)
     st = width * (band[1] - band[0]) / (time.perf_counter() - t1) / 1e6
+    _, _, stats = oracle_ffi.render(scene, width, height, want_rgb=False, want_stats=True, threads=threads)
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -92,6 +93,7 @@ def cpu_baseline(scene, width, height, budget_s=12.0):
         "sample": f"{frames} whole frame(s) of the same workload ({width}x{height}), {el:.1f} s wall, {threads} threads; "
                   f"1-thread figure on the middle quarter band: {st:.3f} Mrays/s",
         "ms_per_frame": round(el / frames * 1e3, 2), "single_thread_mrays": round(st, 3), "cpu": cpu_model,
+        "shadow_rays_per_frame": int(stats["shadow_rays"]),     # counted by the instrumented oracle
     }
 
 
@@ -283,6 +285,10 @@ def main():
                                                 "frac": round(a1 / HBM_PEAK_GBS, 5), "note": "one launch at a time, nothing overlapped"}
         if not args.no_cpu_baseline and n == 1:
             out["cpu_baseline"] = cpu_baseline(scene, W, H)
+            # second column of SURVEY.md §8(d): primary + shadow rays, the shadow rays counted by the oracle
+            shadow = out["cpu_baseline"]["shadow_rays_per_frame"]
+            out["total_rays"] = {"primary_per_frame": W * H, "shadow_per_frame": shadow,
+                                 "value": round((W * H + shadow) / (ms_per_step * 1e-3) / 1e6, 2), "unit": "Mrays/s"}
         if args.check:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_ffi

@@ -93,14 +93,17 @@ class FrameSharder:
     """
 
     def __init__(self, renderers, width: int, height: int, rank: int, world: int, force_gather: bool = False,
-                 pipeline: bool = True):
+                 pipeline: bool = True, device=None):
+        """`device`: where the output tensors live; default the current GPU.  A CPU device (tests/test_dist_gloo.py:
+        gloo, stand-in renderers) runs the same slot rotation and exchange without streams."""
         import torch
         if not isinstance(renderers, (list, tuple)):
             renderers = [renderers]
         if not pipeline:
             renderers = renderers[:1]
         self.W, self.H, self.rank, self.world = width, height, rank, world
-        dev = torch.device("cuda", torch.cuda.current_device())
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.on_gpu = dev.type == "cuda"
         self.local_rows = local_tile_count(height, rank, world) * TILE_ROWS
         self.exchange = world > 1 or force_gather      # force_gather: run the plane/gather/scatter path with one rank
         self.depth = len(renderers)
@@ -114,8 +117,9 @@ class FrameSharder:
             s.r = r
             # The render kernels, the tensors below and what RCCL synchronises with must share ONE real stream per
             # slot.  torch's default stream has handle 0, which the C-ABI reads as "the context's own stream": never it.
-            s.stream = torch.cuda.Stream(device=dev)
-            r.set_stream(s.stream.cuda_stream)
+            s.stream = torch.cuda.Stream(device=dev) if self.on_gpu else None
+            if self.on_gpu:
+                r.set_stream(s.stream.cuda_stream)
             s.framebuffer = s.plane = s.gathered = s.work = s.scattered = None
             s.frames = 0                         # frames submitted to this slot
             if not self.exchange:
@@ -134,7 +138,7 @@ class FrameSharder:
         self.side = None
         if self.exchange and rank == 0:
             self._root_fb = torch.zeros(width * height * 4, dtype=torch.int32, device=dev)
-            self.side = torch.cuda.Stream(device=dev) if pipeline else None
+            self.side = torch.cuda.Stream(device=dev) if (pipeline and self.on_gpu) else None
 
     @property
     def framebuffer(self):
@@ -155,6 +159,11 @@ class FrameSharder:
                 slot.r.set_objects(objects)
             slot.r.render_async()
             return
+        if not self.on_gpu:
+            if objects is not None:
+                slot.r.set_objects(objects)
+            self._render_and_gather(slot)
+            return
         with torch.cuda.stream(slot.stream):
             if objects is not None:
                 slot.r.set_objects(objects)
@@ -163,11 +172,10 @@ class FrameSharder:
     def _render_and_gather(self, slot):
         import torch
         import torch.distributed as td
-        cur = torch.cuda.current_stream()
         if slot.work is not None:
-            slot.work.wait()                        # stream-level: this slot's plane has left the GPU
+            slot.work.wait()                        # stream-level on the GPU: this slot's plane has left the device
         if self.rank == 0 and slot.scattered is not None:
-            cur.wait_event(slot.scattered)          # this slot's gather buffer has been consumed by the reassembly
+            torch.cuda.current_stream().wait_event(slot.scattered)   # this slot's gather buffer has been consumed by the reassembly
         slot.r.render_async()
         glist = list(slot.gathered.unbind(0)) if self.rank == 0 else None
         work = td.gather(slot.plane, glist, dst=0, async_op=True)      # the one exchange step of the frame

@@ -80,3 +80,90 @@ def test_sharded_frame_equals_single_frame(tmp_path, world):
     np.save(fp, frame)
     mp.spawn(_worker, args=(world, _free_port(), W, H, fp, op), nprocs=world, join=True)
     assert np.array_equal(np.load(op), frame)
+
+
+class _OracleSlot:
+    """Stand-in for one frame slot's context on a machine without a GPU: the same calls dist.FrameSharder makes
+    on a Renderer, answered by the CPU oracle and numpy (test infrastructure, like the oracle itself)."""
+
+    def __init__(self, scene, W, H):
+        self.scene, self.W, self.H = scene, W, H
+        self.objects = None
+        self.rows = (0, 1, False)
+        self.plane_ptr = 0
+
+    def set_rows(self, first, step, plane):
+        self.rows = (first, step, plane)
+
+    def set_plane_output(self, ptr):
+        self.plane_ptr = ptr
+
+    def set_objects(self, objects_bytes):
+        self.objects = np.array(objects_bytes, dtype=np.uint8, copy=True)
+
+    def render_async(self):
+        import ctypes as C
+        first, step, plane = self.rows
+        assert plane and self.plane_ptr
+        px, _, _ = oracle_ffi.render(self.scene, self.W, self.H, want_rgb=False, objects=self.objects)
+        frame = px["rgba"].view(np.uint32).reshape(self.H, self.W)
+        mine = rdist.extract_plane(frame, self.W, self.H, first, step)
+        C.memmove(self.plane_ptr, mine.ctypes.data, mine.nbytes)
+
+    def scatter_colour_plane(self, planes_ptr, out_ptr, W, H, world, stride_words, stream=None):
+        import ctypes as C
+        planes = np.ctypeslib.as_array(C.cast(planes_ptr, C.POINTER(C.c_uint32)), shape=(world, stride_words))
+        out = rdist.reassemble_planes(planes, W, H, world)
+        C.memmove(out_ptr, out.ctypes.data, out.nbytes)
+
+
+def _sharder_worker(rank, world, port, W, H, frames, snap_path, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from relativitypathtracer_amd import Scene
+        scene = Scene.from_file("shadows")
+        snaps = np.load(snap_path)                      # Object[] of every frame, computed once by the test
+        slots = [_OracleSlot(scene, W, H) for _ in range(3)]
+        sharder = rdist.FrameSharder(slots, W, H, rank, world, device="cpu")
+        assert sharder.exchange and sharder.depth == 3
+        seen = []
+        for f in range(frames):
+            sharder.render_and_gather(snaps[f])
+            if rank == 0:                               # without streams the root reassembles at once
+                seen.append(sharder.framebuffer.numpy().view(np.uint8).reshape(H * W, 16)[:, 8:12].copy().view(np.uint32)[:, 0])
+        for s in sharder.slots:
+            if s.work is not None:
+                s.work.wait()
+        td.barrier()
+        if rank == 0:
+            np.save(out_path, np.stack(seen))
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_frame_sharder_three_frames_in_flight(tmp_path, world):
+    """dist.FrameSharder itself, world 2 and 3 over gloo: three frame slots rotating over seven different frames
+    (camera clock running), one gather per frame; rank 0's framebuffer after every frame must be that frame."""
+    from relativitypathtracer_amd import Scene
+    W, H, frames = 64, 77, 7
+    scene = Scene.from_file("shadows")
+    scene.set_paused(False)
+    scene.set_camera((0, 0, 0), 14.0)
+    snaps, want = [], []
+    for f in range(frames):
+        scene.advance_time(400)
+        scene.update_objects()
+        snaps.append(scene.buffers()["objects"].copy())
+        px, _, _ = oracle_ffi.render(scene, W, H, want_rgb=False)
+        want.append(px["rgba"].view(np.uint32).reshape(H * W).copy())
+    assert any(not np.array_equal(want[0], w) for w in want[1:])
+    sp, op = str(tmp_path / "snaps.npy"), str(tmp_path / "out.npy")
+    np.save(sp, np.stack(snaps))
+    mp.spawn(_sharder_worker, args=(world, _free_port(), W, H, frames, sp, op), nprocs=world, join=True)
+    got = np.load(op)
+    for f in range(frames):
+        assert np.array_equal(got[f], want[f]), f"frame {f}"
