@@ -5,6 +5,8 @@ textured and flashing objects with velocities, objects around and behind the cam
 cube / a mesh's bounding box, rotated and non-uniformly scaled meshes, two meshes in one scene (the second
 root's triangle list contains the first mesh's triangles — the reference's quirk), interval 0 with lights.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -75,7 +77,8 @@ def random_scene_text(rng):
     return "\n".join(lines) + "\n", has_textured_sphere
 
 
-@pytest.mark.parametrize("seed", range(48))
+# 48 seeds in the suite; RPT_FUZZ_FIRST / RPT_FUZZ_LAST widen the range for a soak run (round 1: seeds 0..1499 clean)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RPT_FUZZ_FIRST", "0")), int(os.environ.get("RPT_FUZZ_LAST", "48"))))
 def test_random_scene(renderer, seed):
     rng = np.random.default_rng(1000 + seed)
     text, approx = random_scene_text(rng)
@@ -106,3 +109,42 @@ def test_random_scene(renderer, seed):
         else:
             assert np.array_equal(rgb.view(np.uint32), orgb.view(np.uint32)), f"seed {seed} variant {variant}: float RGB not bit-identical\n{text}"
             assert np.array_equal(px["rgba"], opx["rgba"]), f"seed {seed} variant {variant}: packed bytes differ\n{text}"
+
+
+@pytest.mark.parametrize("round_", range(int(os.environ.get("RPT_FUZZ_ROUNDS", "8"))))
+def test_random_scenes_three_in_flight(round_):
+    """Three contexts render three DIFFERENT random scenes at once (submitted back to back, nothing waited for in
+    between, kernels overlapping on the device), twice in a row: contexts share no state, so every frame must be
+    what the oracle renders for its own scene."""
+    from relativitypathtracer_amd.renderer import Renderer
+    ctxs, wants = [Renderer(0) for _ in range(3)], []
+    try:
+        for k, r in enumerate(ctxs):
+            rng = np.random.default_rng(50_000 + 3 * round_ + k)
+            text, approx = random_scene_text(rng)
+            scene = Scene()
+            scene.inputScene(text)
+            v = rng.normal(size=3)
+            v = v / np.linalg.norm(v) * rng.choice([0.0, 0.5, 0.95])
+            scene.set_camera(tuple(float(c) for c in v), float(rng.uniform(-3, 20)))
+            scene.update_objects()
+            W, H = [(320, 184), (256, 144), (200, 150)][k]
+            r.upload_scene(scene)
+            r.set_scene_params(scene, W, H)
+            r.set_output(None)
+            opx, _, _ = oracle_ffi.render(scene, W, H, want_rgb=False)
+            wants.append((opx["rgba"], approx, text))
+        for _ in range(2):
+            for r in ctxs:
+                r.render_async()
+        for r in ctxs:
+            r.sync()
+        for r, (want, approx, text) in zip(ctxs, wants):
+            got = r.read_framebuffer()["rgba"]
+            if approx:
+                assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 1, text
+            else:
+                assert np.array_equal(got, want), text
+    finally:
+        for r in ctxs:
+            r.close()
