@@ -972,22 +972,29 @@ __global__ __launch_bounds__(256) void rpt_tile_bin_kernel(const KernelArgs a) {
                     lmax = l > lmax ? l : lmax;
                     u[k] = d * (1.0f / l);
                 }
-                // angles from atan2(|u x v|, u . v): accurate for the tiny angles that strongly anisotropic
-                // object scales produce (acos of a cosine near 1 loses them in fp32)
-                float thTile = 0.0f;
+                // Angles through their SINES, |u x v| (accurate for the tiny angles that strongly anisotropic object
+                // scales produce; acos of a cosine near 1 loses them in fp32), and bounded instead of evaluated:
+                // for an angle below 0.5 rad, sin <= angle <= 1.05 sin.  The tile's half-angle and the sphere's
+                // angular radius are over-estimated, the angle to the sphere's centre is under-estimated.
+                float sTile = 0.0f;
+                bool tile_ok = true;
                 for (int k = 1; k < 5; k++) {
                     const f3 cr = cross(u[0], u[k]);
-                    const float t = atan2f(__builtin_sqrtf(dot(cr, cr)), dot(u[0], u[k]));
-                    thTile = t > thTile ? t : thTile;
+                    const float sn = __builtin_sqrtf(dot(cr, cr));
+                    sTile = sn > sTile ? sn : sTile;
+                    tile_ok = tile_ok && dot(u[0], u[k]) > 0.0f;
                 }
+                const float thTile = 1.05f * sTile;                 // >= the true half-angle while sTile < 0.47
                 const f3 to = mk3(o.cbx - o.ox, o.cby - o.oy, o.cbz - o.oz);
                 const float dist = __builtin_sqrtf(dot(to, to));
-                const bool sane = (lmin > 0.05f * lmax) && (lmax < 1.0e30f) && (dist > 1.05f * o.rb) && (dist < 1.0e30f) && (thTile < 0.25f);
+                const bool sane = tile_ok && (sTile < 0.2f) && (lmin > 0.05f * lmax) && (lmax < 1.0e30f) && (dist > 1.05f * o.rb) && (dist < 1.0e30f);
                 if (sane) {
                     const f3 ca = cross(u[0], to);
-                    const float ang = atan2f(__builtin_sqrtf(dot(ca, ca)), dot(u[0], to));
-                    const float thObj = asinf(fminf(o.rb / dist, 1.0f));
-                    keep = !(ang > thObj + 1.5f * thTile + 1.0e-4f);     // NaN anywhere -> keep
+                    const float sinAng = __builtin_sqrtf(dot(ca, ca)) / dist;
+                    const float angLow = dot(u[0], to) > 0.0f ? sinAng : 1.0f;   // angle >= its sine; behind: >= pi/2 > 1
+                    const float xs_ = o.rb / dist;
+                    const float thObj = xs_ < 0.45f ? 1.05f * xs_ : asinf(fminf(xs_, 1.0f));   // asin(x) <= 1.05 x below 0.45; near objects pay for the asin
+                    keep = !(angLow > thObj + 1.5f * thTile + 1.0e-4f);     // NaN anywhere -> keep
                 }
             }
             if (keep) mask |= 1ull << i;
