@@ -396,3 +396,28 @@ def test_hip_frame_against_the_reference_screenshots(renderer, shot):
         assert (d > 1).sum() <= 4 and (d > 0).mean() < 0.02
     else:
         assert (d > 2).mean() < 5e-4
+
+
+def test_bench_exchange_path_over_rccl_with_one_rank(tmp_path):
+    """bench.py's N > 1 frame path — colour planes, ONE RCCL gather per frame, root reassembly, three frames in
+    flight — run as a real torch.distributed job of one rank (RPT_FORCE_DIST), camera clock running so that every
+    frame differs; its own --check compares the root's last framebuffer with the oracle."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {**os.environ, "RPT_FORCE_DIST": "1", "RPT_BENCH_ANIMATE": "1"}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "14", "--warmup", "2",
+           "--workload", "shadows", "--width", "1280", "--height", "720", "--no-cpu-baseline", "--check"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["check"] == "framebuffer rows identical to the oracle", out["check"]
+    assert out["config"]["frames_in_flight"] == 3 and out["n_gpus"] == 1
