@@ -271,12 +271,12 @@ def main():
         }
         # HBM traffic of the same launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
         # WRITE_SIZE, MI355X_MICROARCH.md §HBM); PMC cannot be collected from inside this process
-        prof = os.path.join(ROOT, "profiles", "r01_final_bunny4k_pmc_summary.json")
+        prof = os.path.join(ROOT, "profiles", "r01_final2_bunny4k_pmc_summary.json")
         if (args.workload, W, H, n, args.variant) == ("bunny", 3840, 2160, 1, 0) and not force_dist and os.path.exists(prof):
             try:
                 d = json.load(open(prof))["derived"]
                 out["roofline"]["traffic"] = int(sum(v for k, v in d.items() if k.startswith("hbm_")))
-                out["roofline"]["traffic_source"] = "profiles/r01_final_bunny4k_pmc_summary.json (rocprofv3 --pmc, same command)"
+                out["roofline"]["traffic_source"] = "profiles/r01_final2_bunny4k_pmc_summary.json (rocprofv3 --pmc, same command; tools/profile.sh + tools/pmc_summary.py)"
             except Exception:
                 pass
         if blocking_kernel_ms:
