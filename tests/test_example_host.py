@@ -82,3 +82,51 @@ def test_example_host_frames_in_flight(tmp_path):
     s.update_objects()
     opx, _, _ = oracle_ffi.render(s, W, H, want_rgb=False)
     assert np.array_equal(img, opx["rgba"].reshape(H, W, 4)[::-1, :, :3])
+
+
+def build_multi_gpu(tmp_path):
+    exe = str(tmp_path / "rpt_multi_gpu")
+    cmd = ["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", f"-I{ROOT}/include", "-I/opt/rocm/include",
+           f"{ROOT}/examples/rpt_multi_gpu_main.cpp", "-o", exe, f"-L{PKG}", "-lrpt_hip", "-lrpt_scene", "-L/opt/rocm/lib",
+           "-lamdhip64", "-lrccl", f"-Wl,-rpath,{PKG}", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return exe
+
+
+def test_multi_gpu_example_builds_and_fails_loudly_without_gpu(tmp_path):
+    import torch
+    exe = build_multi_gpu(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    with open(os.path.join(ASSETS, "Scenes", "shadows.txt")) as f:
+        p = subprocess.run([exe, "64", "48", str(tmp_path / "o.ppm"), "3"], stdin=f, capture_output=True, text=True,
+                           env={**os.environ, "RPT_ASSETS": ASSETS})
+    assert p.returncode == 1 and "no usable gfx950 device" in p.stderr
+
+
+@pytest.mark.gpu
+def test_multi_gpu_example_matches_oracle(tmp_path):
+    """The native C++ multi-GPU host (row tiles -> colour planes -> ONE ncclGather -> root reassembly, three frames
+    in flight) on the GPUs this box has (one: the gather is then GPU 0 to itself): 20 animated frames, the PPM
+    holds the last."""
+    import oracle_ffi
+    from relativitypathtracer_amd import Scene
+    exe = build_multi_gpu(tmp_path)
+    out = tmp_path / "multi.ppm"
+    W, H, frames = 320, 184, 20
+    with open(os.path.join(ASSETS, "Scenes", "shadows.txt")) as f:
+        p = subprocess.run([exe, str(W), str(H), str(out), str(frames), "1"], stdin=f, capture_output=True, text=True,
+                           env={**os.environ, "RPT_ASSETS": ASSETS, "RPT_T0": "16"}, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert f"{frames} frames of {W}x{H}, 3 in flight" in p.stderr
+    data = out.read_bytes()
+    header = f"P6\n{W} {H}\n255\n".encode()
+    img = np.frombuffer(data[len(header):], np.uint8).reshape(H, W, 3)
+    s = Scene.from_file("shadows")
+    s.set_camera((0, 0, 0), 16.0)
+    s.set_paused(False)
+    for _ in range(frames):
+        s.advance_time(16)
+    s.update_objects()
+    opx, _, _ = oracle_ffi.render(s, W, H, want_rgb=False)
+    assert np.array_equal(img, opx["rgba"].reshape(H, W, 4)[::-1, :, :3])
