@@ -129,6 +129,8 @@ def main():
         n = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():      # launcher narrowed the visible devices to one per process
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     force_dist = os.environ.get("RPT_FORCE_DIST") == "1" and "RANK" in os.environ   # rehearse the N>1 path with one rank
     if n > 1 or force_dist:
