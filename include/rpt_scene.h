@@ -15,7 +15,7 @@
  *   rpt_scene_advance_time     render()                   Render.cpp:177
  *   rpt_scene_toggle_interval  render(), I key            Render.cpp:136-147
  *   rpt_scene_reset_velocity   render(), R key            Render.cpp:149-156
- *   rpt_write_ppm              drawGL() (headless stand-in for the GL_POINTS draw) gl_interop.cpp:51-67
+ *   rpt_write_ppm, rpt_write_png  drawGL() (headless stand-in for the GL_POINTS draw) gl_interop.cpp:51-67
  *
  * Conventions: every function returning int returns 0 on success, nonzero on failure, and never
  * throws across the boundary; rpt_scene_last_error() describes the last failure (or holds the
@@ -79,6 +79,8 @@ int rpt_scene_get_mesh_roots(const rpt_scene *s, const int **roots, size_t *coun
 /* framebuffer consumer: write a 16 B/pixel framebuffer (row 0 = bottom, as GL draws it) as a binary
  * PPM with the top row first */
 int rpt_write_ppm(const char *path, const void *pixels16, int width, int height);
+/* the same image as an 8-bit RGB PNG (stored, i.e. uncompressed, zlib stream: no compression library needed) */
+int rpt_write_png(const char *path, const void *pixels16, int width, int height);
 
 #ifdef __cplusplus
 }

@@ -107,6 +107,7 @@ def scene_lib() -> C.CDLL:
             "rpt_scene_get_velocities": (I, [P, C.POINTER(P), C.POINTER(C.c_size_t)]),
             "rpt_scene_get_mesh_roots": (I, [P, C.POINTER(P), C.POINTER(C.c_size_t)]),
             "rpt_write_ppm": (I, [S, P, I, I]),
+            "rpt_write_png": (I, [S, P, I, I]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(lib, name)

@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
+#include <vector>
 
 #include "../../../include/rpt_scene.h"
 #include "rpt_scene.h"
@@ -205,6 +206,72 @@ int rpt_write_ppm(const char *path, const void *pixels16, int width, int height)
     const rpt_pixel *px = (const rpt_pixel *)pixels16;
     for (int row = height - 1; row >= 0; row--)
         for (int x = 0; x < width; x++) std::fwrite(px[(size_t)row * width + x].rgba, 1, 3, f);
+    return std::fclose(f) == 0 ? 0 : 1;
+}
+
+// PNG without a compression library: 8-bit RGB, filter 0, zlib "stored" blocks (RFC 1950/1951), CRC-32 and
+// Adler-32 computed here.  Lossless like the PPM, and every viewer opens it.
+int rpt_write_png(const char *path, const void *pixels16, int width, int height) {
+    if (!path || !pixels16 || width <= 0 || height <= 0) return -1;
+    static uint32_t crc_table[256];
+    if (!crc_table[1])
+        for (uint32_t n = 0; n < 256; n++) {
+            uint32_t c = n;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+            crc_table[n] = c;
+        }
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return 1;
+    auto be32 = [](uint8_t *p, uint32_t v) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; };
+    auto chunk = [&](const char *type, const std::vector<uint8_t> &data) {
+        uint8_t head[8];
+        be32(head, (uint32_t)data.size());
+        std::memcpy(head + 4, type, 4);
+        std::fwrite(head, 1, 8, f);
+        if (!data.empty()) std::fwrite(data.data(), 1, data.size(), f);
+        uint32_t c = 0xffffffffu;
+        for (int i = 4; i < 8; i++) c = crc_table[(c ^ head[i]) & 0xff] ^ (c >> 8);
+        for (uint8_t b : data) c = crc_table[(c ^ b) & 0xff] ^ (c >> 8);
+        uint8_t tail[4];
+        be32(tail, c ^ 0xffffffffu);
+        std::fwrite(tail, 1, 4, f);
+    };
+    const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    std::fwrite(sig, 1, 8, f);
+    std::vector<uint8_t> ihdr(13);
+    be32(&ihdr[0], (uint32_t)width);
+    be32(&ihdr[4], (uint32_t)height);
+    ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;      // 8 bit, truecolour, no interlace
+    chunk("IHDR", ihdr);
+    // raw scanlines, top row first (framebuffer row 0 is the bottom row, gl_interop.cpp:51-67), filter byte 0
+    const rpt_pixel *px = (const rpt_pixel *)pixels16;
+    const size_t stride = 1 + (size_t)width * 3;
+    std::vector<uint8_t> raw(stride * height);
+    for (int row = 0; row < height; row++) {
+        uint8_t *dst = &raw[stride * row];
+        *dst++ = 0;
+        const rpt_pixel *src = px + (size_t)(height - 1 - row) * width;
+        for (int x = 0; x < width; x++, dst += 3) std::memcpy(dst, src[x].rgba, 3);
+    }
+    std::vector<uint8_t> z;
+    z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+    z.push_back(0x78);
+    z.push_back(0x01);
+    uint32_t s1 = 1, s2 = 0;
+    for (size_t off = 0; off < raw.size();) {
+        const size_t n = raw.size() - off < 65535 ? raw.size() - off : 65535;
+        z.push_back(off + n == raw.size() ? 1 : 0);                          // BFINAL, BTYPE = 00 (stored)
+        z.push_back(n & 0xff); z.push_back(n >> 8);
+        z.push_back(~n & 0xff); z.push_back((~n >> 8) & 0xff);
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+        for (size_t i = off; i < off + n; i++) { s1 = (s1 + raw[i]) % 65521u; s2 = (s2 + s1) % 65521u; }
+        off += n;
+    }
+    uint8_t ad[4];
+    be32(ad, (s2 << 16) | s1);
+    z.insert(z.end(), ad, ad + 4);
+    chunk("IDAT", z);
+    chunk("IEND", {});
     return std::fclose(f) == 0 ? 0 : 1;
 }
 

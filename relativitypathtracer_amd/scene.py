@@ -234,3 +234,12 @@ def write_ppm(path: str, pixels16: np.ndarray, width: int, height: int):
     rc = _ffi.scene_lib().rpt_write_ppm(path.encode(), buf.ctypes.data, width, height)
     if rc != 0:
         raise SceneError(f"rpt_write_ppm({path}) failed")
+
+
+def write_png(path: str, pixels16: np.ndarray, width: int, height: int):
+    """The same image as an 8-bit RGB PNG (uncompressed zlib stream, written by the library itself)."""
+    buf = np.ascontiguousarray(pixels16).view(np.uint8)
+    assert buf.size == width * height * 16
+    rc = _ffi.scene_lib().rpt_write_png(path.encode(), buf.ctypes.data, width, height)
+    if rc != 0:
+        raise SceneError(f"rpt_write_png({path}) failed")

@@ -241,3 +241,23 @@ def test_write_ppm_flips_rows(tmp_path):
     assert data.startswith(b"P6\n5 3\n255\n")
     body = np.frombuffer(data[len(b"P6\n5 3\n255\n"):], np.uint8).reshape(H, W, 3)
     assert list(body[:, 0, 0]) == [20, 10, 0]                # top row of the file is the last framebuffer row
+
+
+def test_write_png_decodes_to_the_ppm_image(tmp_path):
+    """rpt_write_png (stored zlib stream, own CRC-32 / Adler-32): an independent decoder must read back exactly the
+    image rpt_write_ppm writes — on a frame wider than one 65 535-byte deflate block per few rows."""
+    from PIL import Image
+    from relativitypathtracer_amd import write_png, write_ppm
+    from relativitypathtracer_amd.renderer import PIXEL_DTYPE
+    rng = np.random.default_rng(5)
+    for W, H in [(5, 3), (1, 1), (700, 123)]:
+        px = np.zeros(W * H, dtype=PIXEL_DTYPE)
+        px["rgba"] = rng.integers(0, 256, size=(W * H, 4), dtype=np.uint8)
+        write_ppm(str(tmp_path / "f.ppm"), px, W, H)
+        write_png(str(tmp_path / "f.png"), px, W, H)
+        a = np.asarray(Image.open(tmp_path / "f.ppm").convert("RGB"))
+        with Image.open(tmp_path / "f.png") as im:
+            assert im.mode == "RGB" and im.size == (W, H)
+            im.verify()                                   # checks every chunk CRC
+        b = np.asarray(Image.open(tmp_path / "f.png"))
+        assert np.array_equal(a, b)
