@@ -29,7 +29,10 @@ def main():
     ap.add_argument("--no-objects", action="store_true", help="do not refresh Object[] every frame (isolates the copy)")
     args = ap.parse_args()
     import ablate
-    if ablate.SCENES.get(args.scene):               # the inline ablation scenes of tools/ablate.py (empty, sphere_light, ...)
+    if args.scene == "dense":                       # NON-REFERENCE: bunny.obj subdivided to 79 488 triangles (tools/dense_mesh.py)
+        import dense_mesh
+        s = dense_mesh.dense_bunny_scene("/tmp/rpt_dense", 2)
+    elif ablate.SCENES.get(args.scene):               # the inline ablation scenes of tools/ablate.py (empty, sphere_light, ...)
         s = Scene()
         s.inputScene(ablate.SCENES[args.scene])
     else:
