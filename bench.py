@@ -295,7 +295,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_ffi
             # every framebuffer that received frames: the root's, or (no exchange) the one of each slot in flight
-            fbs = [frame.framebuffer] if frame.exchange else [sl.framebuffer for sl in frame.slots if sl.frames]
+            fbs = [frame.framebuffer] if (frame.exchange or animate) else [sl.framebuffer for sl in frame.slots if sl.frames]   # animated: the slots hold different instants, only the last frame is the scene's current state
             fbs = [f.cpu().numpy().view(np.uint8).reshape(H, W, 16) for f in fbs]
             ok = True
             for (r0, r1) in [(0, 8), (H * 2 // 5, H * 2 // 5 + 16), (H // 2, H // 2 + 16), (H - 8, H)]:
