@@ -421,3 +421,34 @@ def test_bench_exchange_path_over_rccl_with_one_rank(tmp_path):
     out = json.loads(line)
     assert out["check"] == "framebuffer rows identical to the oracle", out["check"]
     assert out["config"]["frames_in_flight"] == 3 and out["n_gpus"] == 1
+
+
+def test_16k_frame_structure_and_sampled_rows(renderer):
+    """A 15360x8640 frame (132.7 M pixels, 2.1 GB of framebuffer; four times BASELINE's largest): every pixel's
+    (x, y) floats checked on the device, and row bands through sky, silhouette and mesh compared with the oracle."""
+    import torch
+    W, H = 15360, 8640
+    scene = load_config("bunny")
+    _setup(renderer, scene, W, H)
+    fb = torch.zeros((H * W, 4), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream()
+    renderer.set_stream(stream.cuda_stream)
+    renderer.set_output(fb.data_ptr())
+    renderer.render()
+    torch.cuda.synchronize()
+    renderer.set_stream(None)
+    renderer.set_output(None)
+    xy = fb[:, :2].view(torch.float32).view(H, W, 2)
+    assert bool((xy[..., 0] == torch.arange(W, device="cuda", dtype=torch.float32)[None, :]).all())
+    assert bool((xy[..., 1] == torch.arange(H, device="cuda", dtype=torch.float32)[:, None]).all())
+    rgba = fb[:, 2].view(H, W)
+    assert int((rgba >> 24).min()) == 1 and int((rgba >> 24).max()) == 1          # the packed alpha byte
+    hit = (rgba != rgba[0, 0])
+    assert 0.03 < float(hit.float().mean()) < 0.06                                   # the bunny covers ~4.2 % of the frame
+    for r0 in (0, H * 2 // 5, H // 2, H - 8):
+        opx, _, _ = oracle_ffi.render(scene, W, H, rows=(r0, r0 + 8), want_rgb=False)
+        want = opx["rgba"].reshape(H, W, 4)[r0:r0 + 8]
+        got = rgba[r0:r0 + 8].cpu().numpy().view(np.uint8).reshape(8, W, 4)
+        assert np.array_equal(got, want), f"rows {r0}..{r0 + 8}"
+    del fb
+    torch.cuda.empty_cache()
