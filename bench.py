@@ -135,6 +135,8 @@ def main():
     force_dist = os.environ.get("RPT_FORCE_DIST") == "1" and "RANK" in os.environ   # rehearse the N>1 path with one rank
     if n > 1 or force_dist:
         import torch.distributed as td
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"       # RCCL's version banner goes to stdout; this program prints ONE line there
         td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     W, H = args.width, args.height
@@ -158,7 +160,8 @@ def main():
         rr.set_variant(args.variant)
         renderers.append(rr)
     r = renderers[0]
-    frame = rdist.FrameSharder(renderers, W, H, rank, n, force_gather=force_dist, pipeline=pipeline)   # allocates outputs; N == 1 renders straight into the framebuffers
+    frame = rdist.FrameSharder(renderers, W, H, rank, n, force_gather=force_dist, pipeline=pipeline,
+                               plane_bytes=int(os.environ.get("RPT_PLANE_BYTES", "3")))   # allocates outputs; N == 1 renders straight into the framebuffers
 
     animate = os.environ.get("RPT_BENCH_ANIMATE") == "1"     # rehearsal only: every frame differs (camera clock runs)
     clock = [t]
@@ -237,7 +240,7 @@ def main():
         if n == 1 and not force_dist:
             alg = algorithmic_bytes(W, H, n_objects)
         else:
-            alg = 4 * W * frame.local_rows + 320 * n_objects
+            alg = 4 * W * frame.local_rows + 320 * n_objects        # what the render kernel writes (the wire carries plane_bytes/4 of it)
         # Launches of consecutive frames overlap on the device: `overlap` = sum of launch durations / wall time of
         # the region = average number of launches running at once.  A launch's share of the device is then
         # duration / overlap, and achieved = bytes per launch / that (= bytes of all launches / wall time).
@@ -252,7 +255,7 @@ def main():
             "config": {"workload": f"Scenes/{scene_name}.txt {W}x{H}, camera v={list(vel)} t={t}, interval={scene.params['interval']}, "
                                    f"mesh=Models/bunny.obj (StanfordBunny.obj is missing from the reference)" if scene_name == "bunny"
                        else f"Scenes/{scene_name}.txt {W}x{H}, camera v={list(vel)} t={t}",
-                       "frame": "rpt_set_objects + render kernel" + (" + RCCL gather(4 B/px plane) + root scatter" if n > 1 else ""),
+                       "frame": "rpt_set_objects + render kernel" + (f" + RCCL gather({frame.plane_bytes} B/px plane) + root scatter" if n > 1 else ""),
                        "frames_in_flight": frame.depth,
                        "sharding": "interleaved 8-row tiles, tile k -> rank k mod N" if n > 1 else "none",
                        "variant": args.variant},

@@ -137,6 +137,15 @@ int rpt_scatter_colour_plane(rpt_ctx *ctx, const void *planes, void *out16, int 
 int rpt_scatter_colour_plane_on(rpt_ctx *ctx, void *hip_stream, const void *planes, void *out16, int width, int height,
                                 int n_ranks, int plane_stride_words);
 
+/* The exchange at 3 bytes per pixel: the fourth byte of every packed colour is the constant 1 (opencl_kernel.cl:657),
+ * so a rank may send 3/4 of its plane.  rpt_pack_colour_plane3_on rewrites `pixels` (a multiple of 4; a plane of
+ * whole 8-row tiles always is) packed words at `plane4` as 3*pixels bytes at `plane3`, on `hip_stream` (NULL = the
+ * context's launch stream); rpt_scatter_colour_plane3_on is rpt_scatter_colour_plane_on for gathered 3-byte planes
+ * that lie `plane_stride_bytes` apart. */
+int rpt_pack_colour_plane3_on(rpt_ctx *ctx, void *hip_stream, const void *plane4, void *plane3, size_t pixels);
+int rpt_scatter_colour_plane3_on(rpt_ctx *ctx, void *hip_stream, const void *planes3, void *out16, int width, int height,
+                                 int n_ranks, size_t plane_stride_bytes);
+
 /* Diagnostic variant 7 only: loop-iteration counters of the octree walk of the last frame —
  * [0..2] leaf steps / triangle tests / descent steps summed over lanes, [3..5] the same counted
  * once per executing wavefront (lane sum / (64 * wave count) = SIMD utilisation of that loop); [6] longest walk,

@@ -763,6 +763,32 @@ int rpt_scatter_colour_plane_on(rpt_ctx *ctx, void *hip_stream, const void *plan
     return RPT_OK;
 }
 
+int rpt_pack_colour_plane3_on(rpt_ctx *ctx, void *hip_stream, const void *plane4, void *plane3, size_t pixels) {
+    if (!ctx || !plane4 || !plane3) return RPT_ERR_ARG;
+    if (pixels % 4) return fail(ctx, RPT_ERR_ARG, "rpt_pack_colour_plane3: pixel count is not a multiple of 4");
+    if (pixels == 0) return RPT_OK;
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t quads = pixels / 4;
+    hipLaunchKernelGGL(rptd::rpt_pack_plane3_kernel, dim3((unsigned int)((quads + 255) / 256)), dim3(256), 0,
+                       hip_stream ? (hipStream_t)hip_stream : ctx->stream, (const uint4 *)plane4, (uint32_t *)plane3, quads);
+    RPT_HIP(ctx, hipGetLastError());
+    return RPT_OK;
+}
+
+int rpt_scatter_colour_plane3_on(rpt_ctx *ctx, void *hip_stream, const void *planes3, void *out16, int width, int height,
+                                 int n_ranks, size_t plane_stride_bytes) {
+    if (!ctx || !planes3 || !out16 || width <= 0 || height <= 0 || n_ranks <= 0) return RPT_ERR_ARG;
+    const int tiles = (height + RPT_TILE_ROWS - 1) / RPT_TILE_ROWS;
+    const unsigned long long need = 3ull * (unsigned long long)((tiles + n_ranks - 1) / n_ranks) * RPT_TILE_ROWS * (unsigned long long)width;
+    if ((unsigned long long)plane_stride_bytes < need) return fail(ctx, RPT_ERR_ARG, "rpt_scatter_colour_plane3: plane stride smaller than one rank's plane");
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    const dim3 grid((width + 255) / 256, height);
+    hipLaunchKernelGGL(rptd::rpt_scatter_plane3_kernel, grid, dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : ctx->stream,
+                       (const uint8_t *)planes3, (rpt_pixel *)out16, width, height, n_ranks, plane_stride_bytes);
+    RPT_HIP(ctx, hipGetLastError());
+    return RPT_OK;
+}
+
 int rpt_read_counters(rpt_ctx *ctx, unsigned long long out[16]) {
     if (!ctx || !out) return RPT_ERR_ARG;
     if (!ctx->counters.ptr) return fail(ctx, RPT_ERR_STATE, "rpt_read_counters: render with the diagnostic variant (7) first");

@@ -1022,6 +1022,36 @@ __global__ __launch_bounds__(256) void rpt_scatter_plane_kernel(const uint32_t *
     reinterpret_cast<uint4 *>(out16)[(size_t)y * width + x] = px;
 }
 
+// The exchange carries 3 bytes per pixel: the fourth byte of every packed colour is the constant 1
+// (opencl_kernel.cl:657).  Four pixels (four words) of a colour plane become three words, R0 G0 B0 R1 | G1 B1 R2 G2 |
+// B2 R3 G3 B3; a plane's pixel count is a multiple of 8 (whole 8-row tiles).
+__global__ __launch_bounds__(256) void rpt_pack_plane3_kernel(const uint4 *plane4, uint32_t *plane3, size_t quads) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= quads) return;
+    const uint4 p = plane4[q];
+    plane3[3 * q + 0] = (p.x & 0xffffffu) | (p.y << 24);
+    plane3[3 * q + 1] = ((p.y >> 8) & 0xffffu) | (p.z << 16);
+    plane3[3 * q + 2] = ((p.z >> 16) & 0xffu) | (p.w << 8);
+}
+
+// Root-side reassembly of gathered 3-byte planes (rpt_scatter_plane_kernel for the packed form).
+__global__ __launch_bounds__(256) void rpt_scatter_plane3_kernel(const uint8_t *planes, rpt_pixel *out16, int width, int height,
+                                                                int n_ranks, size_t plane_stride_bytes) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= width || y >= height) return;
+    const int tile = y / RPT_TILE_ROWS;
+    const int rank = tile % n_ranks;
+    const int local_row = (tile / n_ranks) * RPT_TILE_ROWS + (y % RPT_TILE_ROWS);
+    const uint8_t *src = planes + (size_t)rank * plane_stride_bytes + 3 * ((size_t)local_row * width + x);
+    uint4 px;
+    px.x = __float_as_uint((float)x);
+    px.y = __float_as_uint((float)y);
+    px.z = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | (1u << 24);
+    px.w = 0u;
+    reinterpret_cast<uint4 *>(out16)[(size_t)y * width + x] = px;
+}
+
 // Known-answer probes of single device functions.
 __global__ void rpt_probe_kernel(int which, const float *in, float *out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

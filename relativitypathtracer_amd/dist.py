@@ -37,6 +37,20 @@ def plane_words(width: int, height: int, world: int) -> int:
     return max_local_tiles(height, world) * TILE_ROWS * width
 
 
+def pack_plane3(plane_words: np.ndarray) -> np.ndarray:
+    """Host restatement of rpt_pack_plane3_kernel: packed R,G,B,1 words -> 3 bytes per pixel."""
+    return np.ascontiguousarray(np.asarray(plane_words, dtype=np.uint32).view(np.uint8).reshape(-1, 4)[:, :3]).reshape(-1)
+
+
+def unpack_plane3(plane_bytes: np.ndarray) -> np.ndarray:
+    """3 bytes per pixel -> packed words with the constant alpha byte 1 (what rpt_scatter_plane3_kernel rebuilds)."""
+    rgb = np.asarray(plane_bytes, dtype=np.uint8).reshape(-1, 3)
+    out = np.empty((rgb.shape[0], 4), dtype=np.uint8)
+    out[:, :3] = rgb
+    out[:, 3] = 1
+    return out.view(np.uint32).reshape(-1)
+
+
 def tile_rows_of_rank(height: int, rank: int, world: int) -> List[range]:
     """Global row ranges (clipped to the image) rendered by `rank`, in local-tile order."""
     out = []
@@ -73,7 +87,7 @@ def reassemble_planes(planes: np.ndarray, width: int, height: int, world: int) -
 
 class _Slot:
     """One frame in flight: a context (rpt_ctx) on its own stream with its own output buffers."""
-    __slots__ = ("r", "stream", "framebuffer", "plane", "gathered", "work", "scattered", "frames")
+    __slots__ = ("r", "stream", "framebuffer", "plane", "plane3", "gathered", "work", "scattered", "frames")
 
 
 class FrameSharder:
@@ -93,9 +107,11 @@ class FrameSharder:
     """
 
     def __init__(self, renderers, width: int, height: int, rank: int, world: int, force_gather: bool = False,
-                 pipeline: bool = True, device=None):
+                 pipeline: bool = True, device=None, plane_bytes: int = 3):
         """`device`: where the output tensors live; default the current GPU.  A CPU device (tests/test_dist_gloo.py:
-        gloo, stand-in renderers) runs the same slot rotation and exchange without streams."""
+        gloo, stand-in renderers) runs the same slot rotation and exchange without streams.
+        `plane_bytes`: bytes per pixel on the wire — 3 (default: the alpha byte of a packed colour is the constant
+        1, so a small kernel drops it before the gather) or 4 (the rendered plane as it is)."""
         import torch
         if not isinstance(renderers, (list, tuple)):
             renderers = [renderers]
@@ -107,6 +123,8 @@ class FrameSharder:
         self.local_rows = local_tile_count(height, rank, world) * TILE_ROWS
         self.exchange = world > 1 or force_gather      # force_gather: run the plane/gather/scatter path with one rank
         self.depth = len(renderers)
+        assert plane_bytes in (3, 4)
+        self.plane_bytes = plane_bytes
         self.pipeline = pipeline
         self.frame = 0
         self.last = None
@@ -120,7 +138,7 @@ class FrameSharder:
             s.stream = torch.cuda.Stream(device=dev) if self.on_gpu else None
             if self.on_gpu:
                 r.set_stream(s.stream.cuda_stream)
-            s.framebuffer = s.plane = s.gathered = s.work = s.scattered = None
+            s.framebuffer = s.plane = s.plane3 = s.gathered = s.work = s.scattered = None
             s.frames = 0                         # frames submitted to this slot
             if not self.exchange:
                 r.set_rows(0, 1, False)
@@ -130,8 +148,11 @@ class FrameSharder:
                 r.set_rows(rank, world, True)
                 s.plane = torch.zeros(words, dtype=torch.int32, device=dev)
                 r.set_plane_output(s.plane.data_ptr())
+                if plane_bytes == 3:
+                    s.plane3 = torch.zeros(words * 3, dtype=torch.uint8, device=dev)
                 if rank == 0:
-                    s.gathered = torch.zeros((world, words), dtype=torch.int32, device=dev)
+                    s.gathered = (torch.zeros((world, words), dtype=torch.int32, device=dev) if plane_bytes == 4 else
+                                  torch.zeros((world, words * 3), dtype=torch.uint8, device=dev))
             self.slots.append(s)
         self.r = self.slots[0].r
         self._root_fb = None
@@ -177,19 +198,24 @@ class FrameSharder:
         if self.rank == 0 and slot.scattered is not None:
             torch.cuda.current_stream().wait_event(slot.scattered)   # this slot's gather buffer has been consumed by the reassembly
         slot.r.render_async()
+        send = slot.plane
+        if self.plane_bytes == 3:                   # drop the constant alpha byte: 3/4 of the bytes on the wire
+            slot.r.pack_colour_plane3(slot.plane.data_ptr(), slot.plane3.data_ptr(), slot.plane.numel(),
+                                      stream=slot.stream.cuda_stream if self.on_gpu else None)
+            send = slot.plane3
         glist = list(slot.gathered.unbind(0)) if self.rank == 0 else None
-        work = td.gather(slot.plane, glist, dst=0, async_op=True)      # the one exchange step of the frame
+        work = td.gather(send, glist, dst=0, async_op=True)      # the one exchange step of the frame
         slot.work = work
+        scatter = slot.r.scatter_colour_plane if self.plane_bytes == 4 else slot.r.scatter_colour_plane3
         if self.rank == 0:
             if self.side is None:
                 work.wait()
-                slot.r.scatter_colour_plane(slot.gathered.data_ptr(), self._root_fb.data_ptr(), self.W, self.H,
-                                            self.world, slot.gathered.shape[1])
+                scatter(slot.gathered.data_ptr(), self._root_fb.data_ptr(), self.W, self.H, self.world, slot.gathered.shape[1])
             else:
                 with torch.cuda.stream(self.side):
                     work.wait()
-                    slot.r.scatter_colour_plane(slot.gathered.data_ptr(), self._root_fb.data_ptr(), self.W, self.H,
-                                                self.world, slot.gathered.shape[1], stream=self.side.cuda_stream)
+                    scatter(slot.gathered.data_ptr(), self._root_fb.data_ptr(), self.W, self.H, self.world,
+                            slot.gathered.shape[1], stream=self.side.cuda_stream)
                     ev = torch.cuda.Event()
                     ev.record(self.side)
                     slot.scattered = ev

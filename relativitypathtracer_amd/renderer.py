@@ -150,6 +150,16 @@ class Renderer:
                                                           C.c_void_p(out16_ptr), width, height, n_ranks, plane_stride_words),
                     "rpt_scatter_colour_plane")
 
+    def pack_colour_plane3(self, plane4_ptr: int, plane3_ptr: int, pixels: int, stream: Optional[int] = None):
+        """4 B/pixel colour plane -> 3 B/pixel (the alpha byte is the constant 1), on `stream` or the launch stream."""
+        self._check(self._lib.rpt_pack_colour_plane3_on(self._h, C.c_void_p(stream or 0), C.c_void_p(plane4_ptr), C.c_void_p(plane3_ptr),
+                                                        int(pixels)), "rpt_pack_colour_plane3_on")
+
+    def scatter_colour_plane3(self, planes3_ptr: int, out16_ptr: int, width: int, height: int, n_ranks: int, stride_bytes: int,
+                              stream: Optional[int] = None):
+        self._check(self._lib.rpt_scatter_colour_plane3_on(self._h, C.c_void_p(stream or 0), C.c_void_p(planes3_ptr), C.c_void_p(out16_ptr),
+                                                           width, height, n_ranks, int(stride_bytes)), "rpt_scatter_colour_plane3_on")
+
     def read_counters(self):
         out = (C.c_uint64 * 16)()
         self._check(self._lib.rpt_read_counters(self._h, out), "rpt_read_counters")

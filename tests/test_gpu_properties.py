@@ -107,6 +107,17 @@ def test_row_tile_shards_reassemble_to_the_single_gpu_frame(renderer, world):
     # and the host restatement of the scatter agrees with the kernel
     host = rdist.reassemble_planes(gathered.cpu().numpy().view(np.uint32), W, H, world)
     assert np.array_equal(host.view(np.uint8), want.view(np.uint8))
+    # the 3-byte form of the exchange (alpha byte dropped before the gather): device pack == host pack, and the
+    # reassembly of the packed planes is the same framebuffer
+    packed = torch.zeros((world, words * 3), dtype=torch.uint8, device="cuda")
+    for rank in range(world):
+        renderer.pack_colour_plane3(gathered[rank].data_ptr(), packed[rank].data_ptr(), words)
+    out3 = torch.zeros(W * H * 4, dtype=torch.int32, device="cuda")
+    renderer.scatter_colour_plane3(packed.data_ptr(), out3.data_ptr(), W, H, world, words * 3)
+    renderer.sync()
+    for rank in range(world):
+        assert np.array_equal(packed[rank].cpu().numpy(), rdist.pack_plane3(gathered[rank].cpu().numpy().view(np.uint32)))
+    assert np.array_equal(out3.cpu().numpy().view(np.uint8), want.view(np.uint8))
     renderer.set_rows(0, 1, False)
     renderer.set_plane_output(None)
 
