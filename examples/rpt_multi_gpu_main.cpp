@@ -1,7 +1,8 @@
 // rpt_multi_gpu_main.cpp — the multi-GPU frame path of INTEGRATION.md §4 as a native C++ host: one process drives
 // every GPU of the node, the frame is sharded by interleaved 8-row tiles (tile k -> GPU k mod N), each GPU renders
-// its tiles into a 4 B/pixel colour plane, ONE ncclGather per frame brings the planes to GPU 0 and
-// rpt_scatter_colour_plane_on expands them into the reference's 16 B/pixel framebuffer.  Three frames are in
+// its tiles into a 4 B/pixel colour plane, drops the constant alpha byte (3 B/pixel on the wire), ONE ncclGather per
+// frame brings the planes to GPU 0 and rpt_scatter_colour_plane3_on expands them into the reference's 16 B/pixel
+// framebuffer.  Three frames are in
 // flight: per GPU three contexts on one resident scene (rpt_share_scene), each with its own stream, and everything
 // a frame slot does — refresh, render, gather, reassembly — is ordered by that one stream.
 //
@@ -72,7 +73,7 @@ int main(int argc, char **argv) {
     const size_t words = ((tiles + n - 1) / n) * RPT_TILE_ROWS * (size_t)width;        // padded: every GPU sends the same count
     std::vector<std::vector<rpt_ctx *>> ctx(n, std::vector<rpt_ctx *>(kSlots, nullptr));
     std::vector<std::vector<hipStream_t>> stream(n, std::vector<hipStream_t>(kSlots));
-    std::vector<std::vector<void *>> plane(n, std::vector<void *>(kSlots, nullptr));
+    std::vector<std::vector<void *>> plane(n, std::vector<void *>(kSlots, nullptr)), plane3 = plane;
     std::vector<int> devs(n);
     for (int d = 0; d < n; d++) {
         devs[d] = d;
@@ -87,13 +88,14 @@ int main(int argc, char **argv) {
             CHECK(hipMalloc(&plane[d][k], words * 4));
             CHECK(hipMemset(plane[d][k], 0, words * 4));
             CHECK(rpt_set_plane_output(ctx[d][k], plane[d][k]));
+            CHECK(hipMalloc(&plane3[d][k], words * 3));
         }
     }
     std::vector<ncclComm_t> comm(n);
     CHECK(ncclCommInitAll(comm.data(), n, devs.data()));
     CHECK(hipSetDevice(0));
     std::vector<void *> gathered(kSlots, nullptr);
-    for (int k = 0; k < kSlots; k++) CHECK(hipMalloc(&gathered[k], (size_t)n * words * 4));
+    for (int k = 0; k < kSlots; k++) CHECK(hipMalloc(&gathered[k], (size_t)n * words * 3));
     void *framebuffer = nullptr;
     CHECK(hipMalloc(&framebuffer, (size_t)width * height * 16));
 
@@ -106,12 +108,13 @@ int main(int argc, char **argv) {
         for (int d = 0; d < n; d++) {
             CHECK(rpt_set_objects(ctx[d][k], desc.objects, (int)desc.object_count));      //      Render.cpp:202
             CHECK(rpt_render_async(ctx[d][k]));                                          // runKernel()
+            CHECK(rpt_pack_colour_plane3_on(ctx[d][k], stream[d][k], plane[d][k], plane3[d][k], words));
         }
         CHECK(ncclGroupStart());                                 // the frame's one exchange step
         for (int d = 0; d < n; d++)
-            CHECK(ncclGather(plane[d][k], gathered[k], words, ncclUint32, 0, comm[d], stream[d][k]));
+            CHECK(ncclGather(plane3[d][k], gathered[k], words * 3, ncclUint8, 0, comm[d], stream[d][k]));
         CHECK(ncclGroupEnd());
-        CHECK(rpt_scatter_colour_plane_on(ctx[0][k], stream[0][k], gathered[k], framebuffer, width, height, n, (int)words));
+        CHECK(rpt_scatter_colour_plane3_on(ctx[0][k], stream[0][k], gathered[k], framebuffer, width, height, n, words * 3));
     }
     for (int d = 0; d < n; d++)
         for (int k = 0; k < kSlots; k++) CHECK(rpt_sync(ctx[d][k]));
