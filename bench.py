@@ -110,7 +110,8 @@ def main():
                     help="frames in flight (contexts on concurrent streams); 1 = one frame at a time, as the reference's runKernel()")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="after timing, compare rank 0's framebuffer with the oracle on a few row bands")
-    ap.add_argument("--gather", default="plane4", choices=["plane4"], help="what is gathered with N>1 (4 B/pixel colour plane)")
+    ap.add_argument("--gather", default=os.environ.get("RPT_GATHER", "plane3"), choices=["plane3", "plane4"],
+                    help="what is gathered with N>1: the colour plane at 3 B/pixel (constant alpha byte dropped) or at 4 B/pixel as rendered")
     args = ap.parse_args()
 
     import numpy as np
@@ -161,7 +162,7 @@ def main():
         renderers.append(rr)
     r = renderers[0]
     frame = rdist.FrameSharder(renderers, W, H, rank, n, force_gather=force_dist, pipeline=pipeline,
-                               plane_bytes=int(os.environ.get("RPT_PLANE_BYTES", "3")))   # allocates outputs; N == 1 renders straight into the framebuffers
+                               plane_bytes=3 if args.gather == "plane3" else 4)   # allocates outputs; N == 1 renders straight into the framebuffers
 
     animate = os.environ.get("RPT_BENCH_ANIMATE") == "1"     # rehearsal only: every frame differs (camera clock runs)
     clock = [t]
