@@ -6,8 +6,8 @@
 //   ./rpt_render 1920 1080 out.ppm [vx vy vz t [frames in_flight]] < assets/reference/Scenes/shadows.txt
 //
 // With `frames` > 1 the clock runs (16 ms per frame, as the reference's timer does) and the frames are rendered with
-// `in_flight` of them overlapping on the GPU: one context per frame slot sharing one resident scene
-// (rpt_share_scene), frame f in slot f mod in_flight.  The PPM is the last frame.
+// `in_flight` of them overlapping on the GPU: rpt::FrameRing (include/rpt_frames.hpp) — one context per frame slot
+// sharing one resident scene (rpt_share_scene), frame f in slot f mod in_flight.  The PPM is the last frame.
 //
 // Textures are read with the library's built-in binary PPM reader (convert the JPEGs first, e.g. with
 // Pillow) — decoding JPEG is the job of CImg/libjpeg in the reference and is outside the render path.
@@ -16,10 +16,12 @@
 #include <cstdlib>
 #include <iostream>
 #include <iterator>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "rpt.h"
+#include "rpt_frames.hpp"
 #include "rpt_scene.h"
 
 int main(int argc, char **argv) {
@@ -65,42 +67,39 @@ int main(int argc, char **argv) {
     float ms = 0;
     rpt_last_frame_ms(ctx, &ms);
     rpt_ctx *last = ctx;
-    std::vector<rpt_ctx *> slots(1, ctx);
     const int frames = argc >= 10 ? std::atoi(argv[8]) : 1, in_flight = argc >= 10 ? std::atoi(argv[9]) : 1;
+    std::unique_ptr<rpt::FrameRing> ring_owner;                  // include/rpt_frames.hpp: one context per frame slot, ONE resident scene
     if (frames > 1 && in_flight >= 1) {
-        for (int k = 1; k < in_flight && !rc; k++) {             // one context per frame slot, ONE resident scene
-            rpt_ctx *c = nullptr;
-            rc = rpt_create(&c, 0);
-            if (!rc) slots.push_back(c);
-            if (!rc) rc = rpt_share_scene(c, ctx);
-            if (!rc) rc = rpt_set_params(c, wp, ambient, width, height, interval);
-            if (!rc) rc = rpt_set_output(c, nullptr);
-        }
+        ring_owner.reset(new rpt::FrameRing(0, in_flight));
+        rpt::FrameRing &ring = *ring_owner;
+        rc = ring.status();
+        if (!rc) rc = ring.upload(desc);
+        if (!rc) rc = ring.set_params(wp, ambient, width, height, interval);
         rpt_scene_set_paused(scene, 0);
         const auto t0 = std::chrono::steady_clock::now();
+        int presented = 0;
         for (int f = 0; f < frames && !rc; f++) {
             rpt_scene_advance_time(scene, 16);                   // render(): cameraPos.x += dt  Render.cpp:177
             rpt_scene_update_objects(scene);
             rpt_scene_get_desc(scene, &desc);
-            last = slots[f % slots.size()];
-            rc = rpt_set_objects(last, desc.objects, (int)desc.object_count);
-            if (!rc) rc = rpt_render_async(last);                // waits for nothing: the slot's stream orders its frames
+            if (ring.submit(desc.objects, (int)desc.object_count)) presented++;   // a finished frame: drawGL() would go here
+            rc = ring.status();
         }
-        for (rpt_ctx *c : slots)
-            if (!rc) rc = rpt_sync(c);
+        if (!rc && ring.drain() == nullptr) rc = ring.status() ? ring.status() : 1;
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (rc) {
-            std::fprintf(stderr, "render: %s\n", rpt_last_error(last));
+            std::fprintf(stderr, "render: %s\n", ring.last_error());
             return 1;
         }
-        std::fprintf(stderr, "%d frames, %d in flight: %.4f ms/frame, %.0f Mrays/s\n", frames, (int)slots.size(), sec / frames * 1e3,
-                     (double)width * height * frames / sec / 1e6);
+        last = ring.newest();
+        std::fprintf(stderr, "%d frames, %d in flight: %.4f ms/frame, %.0f Mrays/s (%d presented while rendering)\n", frames,
+                     ring.frames_in_flight(), sec / frames * 1e3, (double)width * height * frames / sec / 1e6, presented);
     }
     std::vector<unsigned char> fb((size_t)width * height * 16);
     rpt_read_framebuffer(last, fb.data(), fb.size());
     rc = rpt_write_ppm(argv[3], fb.data(), width, height);       // drawGL()                gl_interop.cpp:51
     std::fprintf(stderr, "%dx%d frame in %.3f ms -> %s\n", width, height, ms, argv[3]);
-    for (rpt_ctx *c : slots) rpt_destroy(c);
+    rpt_destroy(ctx);
     rpt_scene_destroy(scene);
     return rc;
 }
