@@ -41,6 +41,11 @@ WORKLOADS = {
     "shadows": ("shadows", (0.0, 0.0, 0.0), 16.0),
     "arch": ("arch", (0.0, 0.0, 0.95), 5.25),
     "cube": ("cube", (0.0, 0.0, 0.0), 0.0),
+    # the reference's other shipped scenes (README.md:96-123), camera states of tests/conftest.py::CONFIGS
+    "cubes": ("cubes", (0.3, 0.0, 0.1), 3.0),
+    "rulers": ("rulers", (0.0, 0.0, 0.0), 2.5),
+    "ladder": ("ladder_paradox", (0.0, 0.0, 0.0), 1.0),
+    "soccer": ("soccer", (0.0, 0.0, 0.0), 2.0),
 }
 
 
@@ -301,12 +306,16 @@ def main():
             # every framebuffer that received frames: the root's, or (no exchange) the one of each slot in flight
             fbs = [frame.framebuffer] if (frame.exchange or animate) else [sl.framebuffer for sl in frame.slots if sl.frames]   # animated: the slots hold different instants, only the last frame is the scene's current state
             fbs = [f.cpu().numpy().view(np.uint8).reshape(H, W, 16) for f in fbs]
-            ok = True
+            worst, differing = 0, 0
             for (r0, r1) in [(0, 8), (H * 2 // 5, H * 2 // 5 + 16), (H // 2, H // 2 + 16), (H - 8, H)]:
                 opx, _, _ = oracle_ffi.render(scene, W, H, rows=(r0, r1), want_rgb=False)
+                want = opx["rgba"].reshape(H, W, 4)[r0:r1].astype(np.int16)
                 for fb in fbs:
-                    ok = ok and np.array_equal(fb[r0:r1, :, 8:12], opx["rgba"].reshape(H, W, 4)[r0:r1])
-            out["check"] = "framebuffer rows identical to the oracle" if ok else "MISMATCH vs oracle"
+                    d = np.abs(fb[r0:r1, :, 8:12].astype(np.int16) - want)
+                    worst, differing = max(worst, int(d.max())), differing + int((d > 0).sum())
+            # textured spheres go through asinf/atan2f (device vs host libm): there the bar is 1 LSB
+            out["check"] = ("framebuffer rows identical to the oracle" if worst == 0 else
+                            f"framebuffer rows within 1 LSB of the oracle ({differing} bytes differ)" if worst == 1 else "MISMATCH vs oracle")
         print(json.dumps(out), flush=True)
     if n > 1 or force_dist:
         td.barrier()

@@ -130,3 +130,11 @@ def test_multi_gpu_example_matches_oracle(tmp_path):
     s.update_objects()
     opx, _, _ = oracle_ffi.render(s, W, H, want_rgb=False)
     assert np.array_equal(img, opx["rgba"].reshape(H, W, 4)[::-1, :, :3])
+
+
+def test_frame_ring_header_is_plain_cxx11(tmp_path):
+    """include/rpt_frames.hpp is header-only C++11 over the C-ABI: it must compile on its own, warnings as errors."""
+    src = tmp_path / "ring.cpp"
+    src.write_text('#include "rpt_frames.hpp"\nint main() { rpt::FrameRing *r = nullptr; (void)r; return 0; }\n')
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-Wpedantic", "-Werror", f"-I{ROOT}/include", "-fsyntax-only", str(src)],
+                   check=True, capture_output=True)
