@@ -33,7 +33,8 @@
  *   min(x,y)   y < x ? y : x;    max(x,y)   x < y ? y : x     (§6.12.4)
  *   sign       +1, -1, +-0 preserved, 0 for NaN
  *   fmod, floor, round (half away from zero), fabs: exact C99 equivalents
- *   asin, atan2: libm single precision (only reachable through textured spheres)
+ *   asin, atan2: implementation-defined in OpenCL (<= 4 ulp); fixed here as the fdlibm single-precision algorithms
+ *                (oracle_asinf / oracle_atan2f below; only reachable through textured spheres)
  *
  * Reference undefined behaviour that is neutralised here — identically in the
  * HIP kernel — without touching any defined result:
@@ -392,6 +393,101 @@ static int intersect_cube(const Scene *s, int index, const Ray4D *ray, Hit *hit)
 }
 
 /* opencl_kernel.cl:335-359 */
+/* asin / atan2 of opencl_kernel.cl:356-357.  OpenCL leaves their last bits to the implementation (<= 4 ulp): the
+ * oracle fixes them as the fdlibm single-precision algorithms below (argument reduction + minimax polynomial, every
+ * step an IEEE +,-,*,/ or sqrt in the stated precision, no contraction), and the HIP kernel restates the same
+ * steps, so the two agree bit for bit where the platforms' libm builds would not. */
+static inline int32_t f2bits(float x) { int32_t i; memcpy(&i, &x, 4); return i; }
+
+static float oracle_asinf(float x) {
+    const float pS0 = 1.6666586697e-01f, pS1 = -4.2743422091e-02f, pS2 = -8.6563630030e-03f, qS1 = -7.0662963390e-01f;
+    const double pio2 = 1.570796326794896558e+00;
+    const int32_t hx = f2bits(x), ix = hx & 0x7fffffff;
+    if (ix >= 0x3f800000) {
+        if (ix == 0x3f800000) return (float)(x * pio2);
+        return (x - x) / (x - x);
+    }
+    if (ix < 0x3f000000) {
+        if (ix < 0x39800000) return x;
+        float t = x * x;
+        float p = t * (pS0 + t * (pS1 + t * pS2));
+        float q = 1.0f + t * qS1;
+        float w = p / q;
+        return x + x * w;
+    }
+    float w0 = 1.0f - fabsf(x);
+    float t = w0 * 0.5f;
+    float p = t * (pS0 + t * (pS1 + t * pS2));
+    float q = 1.0f + t * qS1;
+    double s = sqrt((double)t);
+    float w = p / q;
+    float r = (float)(pio2 - 2.0 * (s + s * (double)w));
+    return hx > 0 ? r : -r;
+}
+
+static float oracle_atanf(float x) {
+    static const float atanhi[4] = { 4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f };
+    static const float atanlo[4] = { 5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f };
+    static const float aT[5] = { 3.3333328366e-01f, -1.9999158382e-01f, 1.4253635705e-01f, -1.0648017377e-01f, 6.1687607318e-02f };
+    const int32_t hx = f2bits(x), ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c800000) {
+        if (ix > 0x7f800000) return x + x;
+        float r = atanhi[3] + atanlo[3];
+        return hx > 0 ? r : -r;
+    }
+    if (ix < 0x3ee00000) {
+        if (ix < 0x39800000) return x;
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {
+            if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }
+            else { id = 1; x = (x - 1.0f) / (x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
+            else { id = 3; x = -1.0f / x; }
+        }
+    }
+    float z = x * x;
+    float w = z * z;
+    float s1 = z * (aT[0] + w * (aT[2] + w * aT[4]));
+    float s2 = w * (aT[1] + w * aT[3]);
+    if (id < 0) return x - x * (s1 + s2);
+    float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return hx < 0 ? -r : r;
+}
+
+static float oracle_atan2f(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int32_t hx = f2bits(x), hy = f2bits(y), ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return oracle_atanf(y);
+    int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) {
+        switch (m) { case 0: case 1: return y; case 2: return pi + tiny; default: return -pi - tiny; }
+    }
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) {
+            switch (m) { case 0: return pi_o_4 + tiny; case 1: return -pi_o_4 - tiny; case 2: return 3.0f * pi_o_4 + tiny; default: return -3.0f * pi_o_4 - tiny; }
+        }
+        switch (m) { case 0: return 0.0f; case 1: return -0.0f; case 2: return pi + tiny; default: return -pi - tiny; }
+    }
+    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 26) { z = pi_o_2 + 0.5f * pi_lo; m &= 1; }
+    else if (k < -26 && hx < 0) z = 0.0f;
+    else z = oracle_atanf(fabsf(y / x));
+    switch (m) {
+    case 0: return z;
+    case 1: return -z;
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+    }
+}
+
 static int intersect_sphere(const Scene *s, const int index, const Ray4D *ray, Hit *hit) {
     const rpt_object *obj = &s->objects[index];
     STAT(sphere_tests);
@@ -416,8 +512,8 @@ static int intersect_sphere(const Scene *s, const int index, const Ray4D *ray, H
     hit->dist = dist / scale;
     hit->normal = normalize3(applyTranspose(obj->InvM, objPt));
     /* M_PI is a double constant in OpenCL C: the divide and add are done in double, rounded once */
-    hit->uv.x = (float)(0.5f + atan2f(objPt.z, objPt.x) / (2 * M_PI));
-    hit->uv.y = (float)(asinf(objPt.y) / M_PI + 0.5f);
+    hit->uv.x = (float)(0.5f + oracle_atan2f(objPt.z, objPt.x) / (2 * M_PI));
+    hit->uv.y = (float)(oracle_asinf(objPt.y) / M_PI + 0.5f);
     return 1;
 }
 
@@ -758,6 +854,11 @@ int rpt_oracle_aabb(const float *bmin, const float *bmax, const float *org, cons
 void rpt_oracle_camray(float x, float y, int w, int h, float *dir3) {
     Ray r = createCamRay(x, y, w, h);
     dir3[0] = r.dir.x; dir3[1] = r.dir.y; dir3[2] = r.dir.z;
+}
+
+void rpt_oracle_asin_atan2(float a, float y, float x, float *out2) {
+    out2[0] = oracle_asinf(a);
+    out2[1] = oracle_atan2f(y, x);
 }
 
 void rpt_oracle_hable(const float *in3, float *out3) {

@@ -80,4 +80,95 @@ RPT_DEV f3 applyTranspose(const rpt_float4 *M, f3 v) {
     return ld3(M[0]) * v.x + ld3(M[1]) * v.y + ld3(M[2]) * v.z;
 }
 
+
+// asin and atan2 of the textured-sphere (u,v) (opencl_kernel.cl:356-357).  OpenCL leaves their last bits to the
+// implementation (<= 4 ulp), so no particular rounding is "the reference's"; what matters here is that the oracle and
+// this kernel agree bit for bit.  Both therefore carry the SAME explicit algorithm (the fdlibm single-precision
+// kernels: argument reduction + minimax polynomial, every operation an IEEE fp32/fp64 +,-,*,/ or sqrt, no
+// contraction) instead of their platforms' libm.  Accuracy: asin < 1 ulp, atan2 < 2 ulp (tests/test_oracle.py).
+RPT_DEV float rpt_asinf(float x) {
+    const float pS0 = 1.6666586697e-01f, pS1 = -4.2743422091e-02f, pS2 = -8.6563630030e-03f, qS1 = -7.0662963390e-01f;
+    const double pio2 = 1.570796326794896558e+00;
+    const int hx = __float_as_int(x);
+    const int ix = hx & 0x7fffffff;
+    if (ix >= 0x3f800000) {                        // |x| >= 1
+        if (ix == 0x3f800000) return (float)(x * pio2);
+        return (x - x) / (x - x);                  // NaN
+    }
+    if (ix < 0x3f000000) {                         // |x| < 0.5
+        if (ix < 0x39800000) return x;             // |x| < 2^-12
+        const float t = x * x;
+        const float p = t * (pS0 + t * (pS1 + t * pS2));
+        const float q = 1.0f + t * qS1;
+        const float w = p / q;
+        return x + x * w;
+    }
+    const float w0 = 1.0f - __builtin_fabsf(x);
+    const float t = w0 * 0.5f;
+    const float p = t * (pS0 + t * (pS1 + t * pS2));
+    const float q = 1.0f + t * qS1;
+    const double s = __builtin_sqrt((double)t);
+    const float w = p / q;
+    const float r = (float)(pio2 - 2.0 * (s + s * (double)w));
+    return hx > 0 ? r : -r;
+}
+
+RPT_DEV float rpt_atanf(float x) {
+    const float aT0 = 3.3333328366e-01f, aT1 = -1.9999158382e-01f, aT2 = 1.4253635705e-01f, aT3 = -1.0648017377e-01f, aT4 = 6.1687607318e-02f;
+    const int hx = __float_as_int(x);
+    const int ix = hx & 0x7fffffff;
+    if (ix >= 0x4c800000) {                        // |x| >= 2^26
+        if (ix > 0x7f800000) return x + x;         // NaN
+        const float r = 1.5707962513e+00f + 7.5497894159e-08f;
+        return hx > 0 ? r : -r;
+    }
+    int id;
+    float hi = 0.0f, lo = 0.0f;
+    if (ix < 0x3ee00000) {                         // |x| < 0.4375
+        if (ix < 0x39800000) return x;             // |x| < 2^-12
+        id = -1;
+    } else {
+        x = __builtin_fabsf(x);
+        if (ix < 0x3f980000) {                     // |x| < 1.1875
+            if (ix < 0x3f300000) { id = 0; hi = 4.6364760399e-01f; lo = 5.0121582440e-09f; x = (2.0f * x - 1.0f) / (2.0f + x); }
+            else { id = 1; hi = 7.8539812565e-01f; lo = 3.7748947079e-08f; x = (x - 1.0f) / (x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000) { id = 2; hi = 9.8279368877e-01f; lo = 3.4473217170e-08f; x = (x - 1.5f) / (1.0f + 1.5f * x); }
+            else { id = 3; hi = 1.5707962513e+00f; lo = 7.5497894159e-08f; x = -1.0f / x; }
+        }
+    }
+    const float z = x * x;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * aT4));
+    const float s2 = w * (aT1 + w * aT3);
+    if (id < 0) return x - x * (s1 + s2);
+    const float r = hi - ((x * (s1 + s2) - lo) - x);
+    return hx < 0 ? -r : r;
+}
+
+RPT_DEV float rpt_atan2f(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int hx = __float_as_int(x), hy = __float_as_int(y);
+    const int ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;      // NaN
+    if (hx == 0x3f800000) return rpt_atanf(y);                 // x = 1
+    int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);               // 2*sign(x) + sign(y)
+    if (iy == 0) return m == 0 || m == 1 ? y : (m == 2 ? pi + tiny : -pi - tiny);
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) return m == 0 ? pi_o_4 + tiny : (m == 1 ? -pi_o_4 - tiny : (m == 2 ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny));
+        return m == 0 ? 0.0f : (m == 1 ? -0.0f : (m == 2 ? pi + tiny : -pi - tiny));
+    }
+    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 26) { z = pi_o_2 + 0.5f * pi_lo; m &= 1; }         // |y/x| > 2^26
+    else if (k < -26 && hx < 0) z = 0.0f;                      // 0 > |y|/x > -2^-26
+    else z = rpt_atanf(__builtin_fabsf(y / x));
+    if (m == 0) return z;
+    if (m == 1) return -z;
+    if (m == 2) return pi - (z - pi_lo);
+    return (z - pi_lo) - pi;
+}
+
 }  // namespace rptd

@@ -626,8 +626,8 @@ RPT_DEV bool sphere_core(const rpt_object &obj, f3 rayToSphere, float c, f3 dir,
     hit.dist = dist / scale;
     hit.normal = normalize(applyTranspose(obj.InvM, objPt));
     if (want_uv) {
-        hit.uv.x = (float)(0.5f + atan2f(objPt.z, objPt.x) / (2 * RPT_PI_D));
-        hit.uv.y = (float)(asinf(objPt.y) / RPT_PI_D + 0.5f);
+        hit.uv.x = (float)(0.5f + rpt_atan2f(objPt.z, objPt.x) / (2 * RPT_PI_D));
+        hit.uv.y = (float)(rpt_asinf(objPt.y) / RPT_PI_D + 0.5f);
     } else {
         hit.uv.x = 0.0f;
         hit.uv.y = 0.0f;
@@ -1088,10 +1088,13 @@ __global__ void rpt_probe_kernel(int which, const float *in, float *out, int n) 
         out[3 * i + 0] = dir.x;
         out[3 * i + 1] = dir.y;
         out[3 * i + 2] = dir.z;
-    } else {
+    } else if (which == 3) {
         out[3 * i + 0] = hable1(in[3 * i + 0]);
         out[3 * i + 1] = hable1(in[3 * i + 1]);
         out[3 * i + 2] = hable1(in[3 * i + 2]);
+    } else {    // asin(a), atan2(b, c) of the textured-sphere (u,v)
+        out[2 * i + 0] = rpt_asinf(in[3 * i + 0]);
+        out[2 * i + 1] = rpt_atan2f(in[3 * i + 1], in[3 * i + 2]);
     }
 }
 

@@ -160,6 +160,8 @@ class FrameSharder:
         if self.exchange and rank == 0:
             self._root_fb = torch.zeros(width * height * 4, dtype=torch.int32, device=dev)
             self.side = torch.cuda.Stream(device=dev) if (pipeline and self.on_gpu) else None
+        if self.on_gpu:
+            torch.cuda.synchronize(dev)     # the zero fills above ran on torch's stream; the slots launch on their own
 
     @property
     def framebuffer(self):

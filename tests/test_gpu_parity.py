@@ -38,7 +38,7 @@ def _render_gpu(r, scene, W, H, variant=0):
 
 SIZES = {"cube": (640, 480), "arch": (480, 270), "arch_t0": (480, 270), "bunny": (480, 270), "shadows": (480, 270),
          "cubes": (480, 270), "rulers": (480, 270), "ladder": (480, 270), "soccer": (320, 184)}
-EXACT = {"cube", "arch", "arch_t0", "bunny", "shadows", "cubes", "rulers", "ladder"}
+EXACT = {"cube", "arch", "arch_t0", "bunny", "shadows", "cubes", "rulers", "ladder", "soccer"}   # every scene: textured spheres too (same explicit asin/atan2 on both sides)
 
 
 VARIANTS = [0, 1, 2, 3, 4, 15, 16, 25, 26, 27, 28, 31]   # include/rpt.h: 0 = default (26); 1 = reference-layout kernel; 2-4 derived layouts; 15/16 pipelined walk; 25-31 per-tile masks

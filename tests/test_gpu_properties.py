@@ -41,9 +41,8 @@ def test_against_committed_golden_frames(renderer, name):
     renderer.render()
     px, rgb = renderer.read_framebuffer(), renderer.read_debug_rgb()
     assert np.abs(rgb - g["rgb"]).max() <= 1e-4
-    if name != "soccer":
-        assert np.array_equal(px["rgba"].reshape(72, 128, 4), g["rgba"])
-        assert np.array_equal(rgb.view(np.uint32), g["rgb"].view(np.uint32))
+    assert np.array_equal(px["rgba"].reshape(72, 128, 4), g["rgba"])
+    assert np.array_equal(rgb.view(np.uint32), g["rgb"].view(np.uint32))
 
 
 FULL = [("bunny", 3840, 2160), ("shadows", 3840, 2160), ("arch", 1920, 1080), ("bunny", 7680, 4320)]
@@ -110,9 +109,10 @@ def test_row_tile_shards_reassemble_to_the_single_gpu_frame(renderer, world):
     # the 3-byte form of the exchange (alpha byte dropped before the gather): device pack == host pack, and the
     # reassembly of the packed planes is the same framebuffer
     packed = torch.zeros((world, words * 3), dtype=torch.uint8, device="cuda")
+    out3 = torch.zeros(W * H * 4, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()                     # torch fills on its own stream, the library launches on the context's
     for rank in range(world):
         renderer.pack_colour_plane3(gathered[rank].data_ptr(), packed[rank].data_ptr(), words)
-    out3 = torch.zeros(W * H * 4, dtype=torch.int32, device="cuda")
     renderer.scatter_colour_plane3(packed.data_ptr(), out3.data_ptr(), W, H, world, words * 3)
     renderer.sync()
     for rank in range(world):
