@@ -856,6 +856,16 @@ void rpt_oracle_camray(float x, float y, int w, int h, float *dir3) {
     dir3[0] = r.dir.x; dir3[1] = r.dir.y; dir3[2] = r.dir.z;
 }
 
+/* out4 = {side, uv'.xyz} of getOppositeBoxSide; out4b = {childIndex, uv'.xyz} of the octree child step */
+void rpt_oracle_walk_steps(const float *scaledDir3, const float *uv3, float *out4, float *out4b) {
+    f3 uv = F3(uv3[0], uv3[1], uv3[2]);
+    int side = getOppositeBoxSide(F3(scaledDir3[0], scaledDir3[1], scaledDir3[2]), &uv);
+    out4[0] = (float)side; out4[1] = uv.x; out4[2] = uv.y; out4[3] = uv.z;
+    f3 uc = F3(uv3[0], uv3[1], uv3[2]);
+    int child = octree_child_step(&uc);
+    out4b[0] = (float)child; out4b[1] = uc.x; out4b[2] = uc.y; out4b[3] = uc.z;
+}
+
 void rpt_oracle_asin_atan2(float a, float y, float x, float *out2) {
     out2[0] = oracle_asinf(a);
     out2[1] = oracle_atan2f(y, x);

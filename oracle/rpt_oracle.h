@@ -47,6 +47,7 @@ int  rpt_oracle_tri(const float *A, const float *B, const float *C, const float 
 int  rpt_oracle_aabb(const float *bmin, const float *bmax, const float *org, const float *dir, float *d2, int *sides2);
 void rpt_oracle_camray(float x, float y, int w, int h, float *dir3);
 void rpt_oracle_hable(const float *in3, float *out3);
+void rpt_oracle_walk_steps(const float *scaledDir3, const float *uv3, float *out4, float *out4b);
 void rpt_oracle_asin_atan2(float a, float y, float x, float *out2);   /* out2 = {asin(a), atan2(y, x)} as the oracle defines them */
 
 #ifdef __cplusplus

@@ -811,8 +811,8 @@ int rpt_read_wave_times(rpt_ctx *ctx, unsigned long long *out, size_t max_words,
 }
 
 int rpt_probe(rpt_ctx *ctx, int which, const void *host_in, void *host_out, int n) {
-    static const int in_w[5] = {15, 12, 4, 3, 3}, out_w[5] = {4, 5, 3, 3, 2};
-    if (!ctx || which < 0 || which > 4 || !host_in || !host_out || n <= 0) return RPT_ERR_ARG;
+    static const int in_w[6] = {15, 12, 4, 3, 3, 6}, out_w[6] = {4, 5, 3, 3, 2, 12};
+    if (!ctx || which < 0 || which > 5 || !host_in || !host_out || n <= 0) return RPT_ERR_ARG;
     RPT_HIP(ctx, hipSetDevice(ctx->device));
     float *d_in = nullptr, *d_out = nullptr;
     RPT_HIP(ctx, hipMalloc((void **)&d_in, sizeof(float) * in_w[which] * n));

@@ -1092,9 +1092,18 @@ __global__ void rpt_probe_kernel(int which, const float *in, float *out, int n) 
         out[3 * i + 0] = hable1(in[3 * i + 0]);
         out[3 * i + 1] = hable1(in[3 * i + 1]);
         out[3 * i + 2] = hable1(in[3 * i + 2]);
-    } else {    // asin(a), atan2(b, c) of the textured-sphere (u,v)
+    } else if (which == 4) {    // asin(a), atan2(b, c) of the textured-sphere (u,v)
         out[2 * i + 0] = rpt_asinf(in[3 * i + 0]);
         out[2 * i + 1] = rpt_atan2f(in[3 * i + 1], in[3 * i + 2]);
+    } else {    // the walk's two pure steps: exit face of a leaf, child selection (general and fast form)
+        const float *p = in + 6 * i;
+        f3 uv = mk3(p[3], p[4], p[5]);
+        const int side = getOppositeBoxSide(makeExitPlan(mk3(p[0], p[1], p[2])), uv);
+        out[12 * i + 0] = (float)side; out[12 * i + 1] = uv.x; out[12 * i + 2] = uv.y; out[12 * i + 3] = uv.z;
+        f3 a = mk3(p[3], p[4], p[5]), b = a;
+        const int ca = octree_child_step(a), cb = octree_child_step_fast(b);
+        out[12 * i + 4] = (float)ca; out[12 * i + 5] = a.x; out[12 * i + 6] = a.y; out[12 * i + 7] = a.z;
+        out[12 * i + 8] = (float)cb; out[12 * i + 9] = b.x; out[12 * i + 10] = b.y; out[12 * i + 11] = b.z;
     }
 }
 

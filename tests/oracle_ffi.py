@@ -60,6 +60,8 @@ def lib() -> C.CDLL:
         l.rpt_oracle_camray.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int, FP]
         l.rpt_oracle_hable.restype = None
         l.rpt_oracle_hable.argtypes = [FP, FP]
+        l.rpt_oracle_walk_steps.restype = None
+        l.rpt_oracle_walk_steps.argtypes = [FP, FP, FP, FP]
         l.rpt_oracle_asin_atan2.restype = None
         l.rpt_oracle_asin_atan2.argtypes = [C.c_float, C.c_float, C.c_float, FP]
         _lib = l

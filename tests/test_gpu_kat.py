@@ -132,3 +132,27 @@ def test_asin_atan2_device_equals_oracle(renderer):
         want[i] = o
     same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
     assert same.all(), x[~same.all(axis=1)][:5]
+
+
+def test_walk_steps_device_equals_oracle(renderer):
+    """getOppositeBoxSide (opencl_kernel.cl:172-198) with the hoisted reciprocals, and the octree child step
+    (:237-238) in its general form and in the kernel's exact fast form for 0 <= uv < 1.5: bit-identical to the
+    oracle on points inside, on and just outside the unit cell, axis-parallel directions, NaN."""
+    lib = oracle_ffi.lib()
+    rng = np.random.default_rng(33)
+    n = 20000
+    x = np.empty((n, 6), dtype=np.float32)
+    d = rng.normal(size=(n, 3))
+    x[:, :3] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    x[:, 3:] = rng.uniform(-0.1, 1.6, size=(n, 3))
+    x[:2000, 3:] = rng.choice([0.0, 0.5, 1.0, 0.49999997, 0.99999994, 1.0000001, 1.4999999, 1.5], size=(2000, 3))
+    x[2000:2300, rng.integers(0, 3)] = 0.0            # axis-parallel: an infinite reciprocal
+    x[2300:2310, 3] = np.nan
+    got = renderer.probe(5, x, 12)
+    a, b = np.zeros(4, dtype=np.float32), np.zeros(4, dtype=np.float32)
+    for i in range(n):
+        lib.rpt_oracle_walk_steps(_fp(x[i, :3].copy()), _fp(x[i, 3:].copy()), _fp(a), _fp(b))
+        for lo, want in ((0, a), (4, b), (8, b)):
+            g = got[i, lo:lo + 4]
+            same = (g.view(np.uint32) == want.view(np.uint32)) | (np.isnan(g) & np.isnan(want))
+            assert same.all(), (i, lo, x[i], g, want)
