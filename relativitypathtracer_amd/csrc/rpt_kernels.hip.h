@@ -71,7 +71,7 @@ struct KernelArgs {
     rpt_pixel *out16;        // 16 B/pixel framebuffer (full frame addressing) or null
     uint32_t *plane;         // compact 4 B/pixel colour plane (local tile addressing) or null
     float *debug_rgb;        // 3 floats/pixel, full frame addressing, or null
-    unsigned long long *wave_times; // diagnostic builds only (variant 7): per wave {start, end} of s_memrealtime (100 MHz)
+    unsigned long long *wave_times; // diagnostic build only (variant 11): ten words per wave, {start, end} of s_memrealtime (100 MHz) + loop accounting
     unsigned long long *counters;   // diagnostic builds only (variant 7): [0..2] lane-level leaf/tri/descent
                                     // iterations, [3..5] the same counted once per executing wave
     float hable_wp[3];       // hable(white_point), host-computed
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 __global__ __launch_bounds__(256) void rpt_render_kernel_primary_only(const KernelArgs a) { render_pixel_body<3>(a); }
 
 // ---------------------------------------------------------------------------------------------
-// Tile binning prepass (one thread per 8x8 tile).  For every object it asks whether ANY primary ray
+// Tile-mask prepass (one thread per 8x8 tile).  For every object it asks whether ANY primary ray
 // of the tile can reach the object's bounding sphere: the tile's rays (object space) lie in a cone
 // around the centre ray whose half-angle is taken from the four corner rays (of the tile grown by
 // half a pixel) with a 1.5x safety factor; the sphere subtends asin(r/d) around the direction to its
