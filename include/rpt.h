@@ -83,6 +83,12 @@ int rpt_set_output(rpt_ctx *ctx, void *device_ptr_or_null);
  * renders into a compact library-owned plane of 4 B/pixel (the packed R,G,B,1 word only), its
  * k-th local tile holding global tile first_tile + k*tile_step: the unit that is gathered. */
 int rpt_set_rows(rpt_ctx *ctx, int first_tile, int tile_step, int colour_plane);
+/* The general form: per period of `tile_step` tiles this context renders the `run` (a power of two, <= tile_step)
+ * consecutive tiles that start at first_tile; local tile t is global tile (t / run) * tile_step + first_tile + t % run.
+ * rpt_set_rows is run = 1.  Used for the WEIGHTED multi-GPU split: the root of the gather renders `run` tiles of every
+ * period of run + N - 1 straight into the framebuffer (colour_plane = 0) and helper j the single tile run + j - 1 into
+ * its plane — the root takes the larger share because its pixels need no exchange. */
+int rpt_set_tile_pattern(rpt_ctx *ctx, int first_tile, int tile_step, int run, int colour_plane);
 
 /* Launch on this HIP stream (hipStream_t as void*; NULL = the context's own stream). */
 int rpt_set_stream(rpt_ctx *ctx, void *hip_stream);
@@ -145,6 +151,11 @@ int rpt_scatter_colour_plane_on(rpt_ctx *ctx, void *hip_stream, const void *plan
 int rpt_pack_colour_plane3_on(rpt_ctx *ctx, void *hip_stream, const void *plane4, void *plane3, size_t pixels);
 int rpt_scatter_colour_plane3_on(rpt_ctx *ctx, void *hip_stream, const void *planes3, void *out16, int width, int height,
                                  int n_ranks, size_t plane_stride_bytes);
+/* Reassembly for the weighted split: planes3 holds n_ranks gathered 3-byte planes plane_stride_bytes apart (slot 0, the
+ * root's, is not read); the helpers' tiles are written into out16, the root's own tiles (already rendered there) are
+ * left alone. */
+int rpt_scatter_helper_planes3_on(rpt_ctx *ctx, void *hip_stream, const void *planes3, void *out16, int width, int height,
+                                  int n_ranks, int root_run, size_t plane_stride_bytes);
 
 /* Diagnostic variant 7 only: loop-iteration counters of the octree walk of the last frame —
  * [0..2] leaf steps / triangle tests / descent steps summed over lanes, [3..5] the same counted

@@ -141,6 +141,8 @@ HIP_SYMBOLS = {
     "rpt_timed_frames": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "rpt_scatter_colour_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rpt_scatter_colour_plane_on": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rpt_set_tile_pattern": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rpt_scatter_helper_planes3_on": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t]),
     "rpt_pack_colour_plane3_on": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rpt_scatter_colour_plane3_on": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t]),
     "rpt_colour_plane_ptr": (C.c_void_p, [C.c_void_p]),

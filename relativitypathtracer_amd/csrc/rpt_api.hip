@@ -81,7 +81,7 @@ struct rpt_ctx {
     std::vector<hipEvent_t> timing_events;   // pairs: begin,end per frame
     int timing_frames = -1;                  // -1 = timing region not active
     bool want_owned_rgb = false;
-    int first_tile = 0, tile_step = 1;
+    int first_tile = 0, tile_step = 1, run_log2 = 0;
     bool colour_plane = false;
     int variant = 0;
     float last_ms = 0.0f;
@@ -302,11 +302,12 @@ int validate_objects(rpt_ctx *ctx, const rpt_object *objs, int count) {
     return RPT_OK;
 }
 
+int local_tile_count(const rpt_ctx *ctx);
+
 int ensure_outputs(rpt_ctx *ctx) {
     const size_t px = (size_t)ctx->width * ctx->height;
     if (ctx->colour_plane) {
-        const int tiles = (ctx->height + RPT_TILE_ROWS - 1) / RPT_TILE_ROWS;
-        const int local_tiles = ctx->first_tile >= tiles ? 0 : (tiles - ctx->first_tile + ctx->tile_step - 1) / ctx->tile_step;
+        const int local_tiles = local_tile_count(ctx);
         if (!ctx->external_plane)
             if (int rc = reserve(ctx, ctx->owned_plane, (size_t)local_tiles * RPT_TILE_ROWS * ctx->width * 4)) return rc;
     } else if (!ctx->external_out) {
@@ -321,10 +322,14 @@ int ensure_outputs(rpt_ctx *ctx) {
     return RPT_OK;
 }
 
+// local tiles of this context: local tile t is global tile (t >> run_log2) * tile_step + first_tile + (t & (run - 1))
 int local_tile_count(const rpt_ctx *ctx) {
     const int tiles = (ctx->height + RPT_TILE_ROWS - 1) / RPT_TILE_ROWS;
+    const int run = 1 << ctx->run_log2;
     if (ctx->first_tile >= tiles) return 0;
-    return (tiles - ctx->first_tile + ctx->tile_step - 1) / ctx->tile_step;
+    const int full_periods = (tiles - ctx->first_tile) / ctx->tile_step;          // periods whose whole run may lie inside
+    const int rest = tiles - ctx->first_tile - full_periods * ctx->tile_step;    // tiles of the last, partial period
+    return full_periods * run + (rest < run ? rest : run);
 }
 
 int launch(rpt_ctx *ctx) {
@@ -368,6 +373,7 @@ int launch(rpt_ctx *ctx) {
     a.interval = ctx->interval;
     a.first_tile = ctx->first_tile;
     a.tile_step = ctx->tile_step;
+    a.run_log2 = ctx->run_log2;
 
     const int tiles = local_tile_count(ctx);
     if (tiles == 0) return RPT_OK;
@@ -586,9 +592,16 @@ int rpt_set_output(rpt_ctx *ctx, void *device_ptr_or_null) {
 }
 
 int rpt_set_rows(rpt_ctx *ctx, int first_tile, int tile_step, int colour_plane) {
-    if (!ctx || first_tile < 0 || tile_step < 1) return RPT_ERR_ARG;
+    return rpt_set_tile_pattern(ctx, first_tile, tile_step, 1, colour_plane);
+}
+
+int rpt_set_tile_pattern(rpt_ctx *ctx, int first_tile, int tile_step, int run, int colour_plane) {
+    if (!ctx || first_tile < 0 || tile_step < 1 || run < 1 || run > tile_step || (run & (run - 1))) return RPT_ERR_ARG;
+    int lg = 0;
+    while ((1 << lg) < run) lg++;
     ctx->first_tile = first_tile;
     ctx->tile_step = tile_step;
+    ctx->run_log2 = lg;
     ctx->colour_plane = colour_plane != 0;
     return RPT_OK;
 }
@@ -785,6 +798,21 @@ int rpt_scatter_colour_plane3_on(rpt_ctx *ctx, void *hip_stream, const void *pla
     const dim3 grid((width + 255) / 256, height);
     hipLaunchKernelGGL(rptd::rpt_scatter_plane3_kernel, grid, dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : ctx->stream,
                        (const uint8_t *)planes3, (rpt_pixel *)out16, width, height, n_ranks, plane_stride_bytes);
+    RPT_HIP(ctx, hipGetLastError());
+    return RPT_OK;
+}
+
+int rpt_scatter_helper_planes3_on(rpt_ctx *ctx, void *hip_stream, const void *planes3, void *out16, int width, int height,
+                                  int n_ranks, int root_run, size_t plane_stride_bytes) {
+    if (!ctx || !planes3 || !out16 || width <= 0 || height <= 0 || n_ranks < 2 || root_run < 1) return RPT_ERR_ARG;
+    const int period = root_run + n_ranks - 1;
+    const int tiles = (height + RPT_TILE_ROWS - 1) / RPT_TILE_ROWS;
+    const unsigned long long need = 3ull * (unsigned long long)((tiles + period - 1) / period) * RPT_TILE_ROWS * (unsigned long long)width;
+    if ((unsigned long long)plane_stride_bytes < need) return fail(ctx, RPT_ERR_ARG, "rpt_scatter_helper_planes3: plane stride smaller than one helper's plane");
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    const dim3 grid((width + 255) / 256, height);
+    hipLaunchKernelGGL(rptd::rpt_scatter_helper_planes3_kernel, grid, dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : ctx->stream,
+                       (const uint8_t *)planes3, (rpt_pixel *)out16, width, height, period, root_run, plane_stride_bytes);
     RPT_HIP(ctx, hipGetLastError());
     return RPT_OK;
 }

@@ -82,7 +82,8 @@ struct KernelArgs {
     int object_count;
     int width, height;
     int interval;
-    int first_tile, tile_step;
+    int first_tile, tile_step;      // local tile t holds global tile (t >> run_log2) * tile_step + first_tile + (t & (run - 1))
+    int run_log2;                   // run = 1 << run_log2 consecutive tiles per period of tile_step tiles (rpt_set_tile_pattern)
     // per-tile object masks: 8x8-pixel tiles of this context's rows, classified once per frame by rpt_tile_bin_kernel
     int tiles_x, n_tiles;                    // tiles per row, tiles in this context's rows
     unsigned long long *tile_masks;          // [n_tiles] bit i = primary rays of the tile may hit object i (i < 64)
@@ -869,7 +870,8 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
     const int row_in_tile = lane >> 3;
     const int x_coord = (int)blockIdx.x * 32 + wave * 8 + (lane & 7);
     const int local_row = tile_row * RPT_TILE_ROWS + row_in_tile;
-    const int y_coord = (a.first_tile + tile_row * a.tile_step) * RPT_TILE_ROWS + row_in_tile;
+    const int global_tile = (tile_row >> a.run_log2) * a.tile_step + a.first_tile + (tile_row & ((1 << a.run_log2) - 1));
+    const int y_coord = global_tile * RPT_TILE_ROWS + row_in_tile;
     if (x_coord >= a.width || y_coord >= a.height) return;   // the reference has no guard (UB)
 
     f3 color;
@@ -950,7 +952,8 @@ __global__ __launch_bounds__(256) void rpt_tile_bin_kernel(const KernelArgs a) {
     unsigned long long mask = 0;
     if (valid) {
         const int tx = tile % a.tiles_x, trow = tile / a.tiles_x;
-        const float x0 = (float)(tx * 8), y0 = (float)((a.first_tile + trow * a.tile_step) * RPT_TILE_ROWS);
+        const float x0 = (float)(tx * 8);
+        const float y0 = (float)(((trow >> a.run_log2) * a.tile_step + a.first_tile + (trow & ((1 << a.run_log2) - 1))) * RPT_TILE_ROWS);
         const float xs[5] = {x0 + 3.5f, x0 - 0.5f, x0 + 7.5f, x0 - 0.5f, x0 + 7.5f};
         const float ys[5] = {y0 + 3.5f, y0 - 0.5f, y0 - 0.5f, y0 + 7.5f, y0 + 7.5f};
         f3 nd[5];
@@ -1043,6 +1046,28 @@ __global__ __launch_bounds__(256) void rpt_scatter_plane3_kernel(const uint8_t *
     const int tile = y / RPT_TILE_ROWS;
     const int rank = tile % n_ranks;
     const int local_row = (tile / n_ranks) * RPT_TILE_ROWS + (y % RPT_TILE_ROWS);
+    const uint8_t *src = planes + (size_t)rank * plane_stride_bytes + 3 * ((size_t)local_row * width + x);
+    uint4 px;
+    px.x = __float_as_uint((float)x);
+    px.y = __float_as_uint((float)y);
+    px.z = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | (1u << 24);
+    px.w = 0u;
+    reinterpret_cast<uint4 *>(out16)[(size_t)y * width + x] = px;
+}
+
+// Reassembly for the weighted split (rpt_set_tile_pattern): per period of `period` tiles the root renders the first
+// `root_run` straight into the framebuffer, helper j (1..n_ranks-1) the tile root_run + j - 1 into its 3-byte plane
+// (local tile = period index).  Only the helpers' tiles are written here; the root's are already in place.
+__global__ __launch_bounds__(256) void rpt_scatter_helper_planes3_kernel(const uint8_t *planes, rpt_pixel *out16, int width, int height,
+                                                                        int period, int root_run, size_t plane_stride_bytes) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= width || y >= height) return;
+    const int tile = y / RPT_TILE_ROWS;
+    const int slot = tile % period;
+    if (slot < root_run) return;
+    const int rank = slot - root_run + 1;
+    const int local_row = (tile / period) * RPT_TILE_ROWS + (y % RPT_TILE_ROWS);
     const uint8_t *src = planes + (size_t)rank * plane_stride_bytes + 3 * ((size_t)local_row * width + x);
     uint4 px;
     px.x = __float_as_uint((float)x);

@@ -35,6 +35,7 @@ class Renderer:
         self.device = device
         self.width = self.height = 0
         self._rows = (0, 1, False)
+        self._run = 1
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
@@ -84,6 +85,13 @@ class Renderer:
     def set_rows(self, first_tile: int = 0, tile_step: int = 1, colour_plane: bool = False):
         self._check(self._lib.rpt_set_rows(self._h, first_tile, tile_step, int(colour_plane)), "rpt_set_rows")
         self._rows = (first_tile, tile_step, colour_plane)
+        self._run = 1
+
+    def set_tile_pattern(self, first_tile: int, tile_step: int, run: int, colour_plane: bool = False):
+        """Per period of `tile_step` tiles, the `run` (power of two) consecutive tiles from first_tile on (rpt_set_rows: run 1)."""
+        self._check(self._lib.rpt_set_tile_pattern(self._h, first_tile, tile_step, run, int(colour_plane)), "rpt_set_tile_pattern")
+        self._rows = (first_tile, tile_step, colour_plane)
+        self._run = run
 
     def set_plane_output(self, device_ptr: Optional[int]):
         self._check(self._lib.rpt_set_plane_output(self._h, C.c_void_p(device_ptr or 0)), "rpt_set_plane_output")
@@ -110,7 +118,10 @@ class Renderer:
     def local_tiles(self) -> int:
         first, step, _ = self._rows
         tiles = (self.height + TILE_ROWS - 1) // TILE_ROWS
-        return 0 if first >= tiles else (tiles - first + step - 1) // step
+        if first >= tiles:
+            return 0
+        full, rest = divmod(tiles - first, step)
+        return full * self._run + min(rest, self._run)
 
     def output_ptr(self) -> int:
         return self._lib.rpt_output_ptr(self._h) or 0
@@ -154,6 +165,11 @@ class Renderer:
         """4 B/pixel colour plane -> 3 B/pixel (the alpha byte is the constant 1), on `stream` or the launch stream."""
         self._check(self._lib.rpt_pack_colour_plane3_on(self._h, C.c_void_p(stream or 0), C.c_void_p(plane4_ptr), C.c_void_p(plane3_ptr),
                                                         int(pixels)), "rpt_pack_colour_plane3_on")
+
+    def scatter_helper_planes3(self, planes3_ptr: int, out16_ptr: int, width: int, height: int, n_ranks: int, root_run: int,
+                               stride_bytes: int, stream: Optional[int] = None):
+        self._check(self._lib.rpt_scatter_helper_planes3_on(self._h, C.c_void_p(stream or 0), C.c_void_p(planes3_ptr), C.c_void_p(out16_ptr),
+                                                            width, height, n_ranks, root_run, int(stride_bytes)), "rpt_scatter_helper_planes3_on")
 
     def scatter_colour_plane3(self, planes3_ptr: int, out16_ptr: int, width: int, height: int, n_ranks: int, stride_bytes: int,
                               stream: Optional[int] = None):

@@ -463,3 +463,42 @@ def test_16k_frame_structure_and_sampled_rows(renderer):
         assert np.array_equal(got, want), f"rows {r0}..{r0 + 8}"
     del fb
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("world,root_run", [(2, 4), (2, 8), (3, 2), (4, 4), (8, 4), (8, 1)])
+def test_weighted_split_reassembles_to_the_single_gpu_frame(renderer, world, root_run):
+    """The weighted multi-GPU split (rpt_set_tile_pattern) with the ranks run one after another on this GPU: per
+    period of root_run + N - 1 tiles the root renders root_run tiles straight into the framebuffer, helper j one
+    tile into its plane; packed to 3 bytes, "gathered", and reassembled by rpt_scatter_helper_planes3 the frame
+    must be the plain render."""
+    import torch
+    scene = load_config("shadows")
+    W, H = 1280, 1000                                # 125 tiles: the last period is partial for every case
+    _setup(renderer, scene, W, H)
+    renderer.render()
+    want = renderer.read_framebuffer()
+    period = root_run + world - 1
+    tiles = rdist.tile_count(H)
+    helper_tiles = (tiles + period - 1) // period    # padded: every helper sends the same count
+    words = helper_tiles * 8 * W
+    fb = torch.zeros(W * H * 4, dtype=torch.int32, device="cuda")
+    planes4 = torch.zeros((world, words), dtype=torch.int32, device="cuda")
+    gathered = torch.zeros((world, words * 3), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    renderer.set_tile_pattern(0, period, root_run, False)      # the root
+    renderer.set_output(fb.data_ptr())
+    renderer.render()
+    assert renderer.local_tiles() == sum(1 for k in range(tiles) if k % period < root_run)
+    for j in range(1, world):                                  # the helpers
+        renderer.set_tile_pattern(root_run + j - 1, period, 1, True)
+        renderer.set_plane_output(planes4[j].data_ptr())
+        renderer.render()
+        assert renderer.local_tiles() == sum(1 for k in range(tiles) if k % period == root_run + j - 1)
+        renderer.pack_colour_plane3(planes4[j].data_ptr(), gathered[j].data_ptr(), words)
+    renderer.scatter_helper_planes3(gathered.data_ptr(), fb.data_ptr(), W, H, world, root_run, words * 3)
+    renderer.sync()
+    got = fb.cpu().numpy().view(want.dtype)
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    renderer.set_rows(0, 1, False)
+    renderer.set_plane_output(None)
+    renderer.set_output(None)
