@@ -166,8 +166,19 @@ def main():
         rr.set_variant(args.variant)
         renderers.append(rr)
     r = renderers[0]
+    # N > 1: how the frame is split.  auto = measure this node (one rank's frame time, the gather's cost
+    # model) and let rank 0 choose between the weighted split, and rendering everything on rank 0 when the exchange
+    # would only slow it down; equal = tile k -> rank k mod N; solo / an integer = force that arrangement.
+    split, split_info, root_run = os.environ.get("RPT_SPLIT", "auto"), None, None
+    if (n > 1 or force_dist) and pipeline and args.gather == "plane3" and split != "equal":
+        if split == "auto":
+            root_run, split_info = rdist.calibrate_split(renderers, scene, W, H, rank, n)
+            if n == 1:
+                root_run = None              # one-rank rehearsal: the measurement ran, there is nothing to split
+        else:
+            root_run = 0 if split == "solo" else int(split)
     frame = rdist.FrameSharder(renderers, W, H, rank, n, force_gather=force_dist, pipeline=pipeline,
-                               plane_bytes=3 if args.gather == "plane3" else 4)   # allocates outputs; N == 1 renders straight into the framebuffers
+                               plane_bytes=3 if args.gather == "plane3" else 4, root_run=root_run)   # allocates outputs; N == 1 renders straight into the framebuffers
 
     animate = os.environ.get("RPT_BENCH_ANIMATE") == "1"     # rehearsal only: every frame differs (camera clock runs)
     clock = [t]
@@ -245,6 +256,8 @@ def main():
         # rank / its mean duration.  With N ranks one launch covers 1/N of the pixels (4 B/px plane).
         if n == 1 and not force_dist:
             alg = algorithmic_bytes(W, H, n_objects)
+        elif frame.weighted or frame.solo:
+            alg = 16 * W * min(frame.local_rows, H) + 320 * n_objects      # rank 0 writes its rows as 16 B/px framebuffer pixels
         else:
             alg = 4 * W * frame.local_rows + 320 * n_objects        # what the render kernel writes (the wire carries plane_bytes/4 of it)
         # Launches of consecutive frames overlap on the device: `overlap` = sum of launch durations / wall time of
@@ -263,7 +276,10 @@ def main():
                        else f"Scenes/{scene_name}.txt {W}x{H}, camera v={list(vel)} t={t}",
                        "frame": "rpt_set_objects + render kernel" + (f" + RCCL gather({frame.plane_bytes} B/px plane) + root scatter" if n > 1 else ""),
                        "frames_in_flight": frame.depth,
-                       "sharding": "interleaved 8-row tiles, tile k -> rank k mod N" if n > 1 else "none",
+                       "sharding": ("none" if n == 1 else "interleaved 8-row tiles, tile k -> rank k mod N" if root_run is None else
+                                    "rank 0 renders the whole frame (the exchange would cost more than it saves)" if root_run == 0 else
+                                    f"weighted: per {root_run + n - 1} tiles rank 0 renders {root_run} in place, ranks 1..{n - 1} one each into 3 B/px planes"),
+                       "split_calibration": split_info,
                        "variant": args.variant},
             "kernel_ms": round(kernel_ms, 4),
             "one_frame_at_a_time": None if blocking_ms is None else {

@@ -804,7 +804,7 @@ int rpt_scatter_colour_plane3_on(rpt_ctx *ctx, void *hip_stream, const void *pla
 
 int rpt_scatter_helper_planes3_on(rpt_ctx *ctx, void *hip_stream, const void *planes3, void *out16, int width, int height,
                                   int n_ranks, int root_run, size_t plane_stride_bytes) {
-    if (!ctx || !planes3 || !out16 || width <= 0 || height <= 0 || n_ranks < 2 || root_run < 1) return RPT_ERR_ARG;
+    if (!ctx || !planes3 || !out16 || width <= 0 || height <= 0 || n_ranks < 1 || root_run < 1) return RPT_ERR_ARG;
     const int period = root_run + n_ranks - 1;
     const int tiles = (height + RPT_TILE_ROWS - 1) / RPT_TILE_ROWS;
     const unsigned long long need = 3ull * (unsigned long long)((tiles + period - 1) / period) * RPT_TILE_ROWS * (unsigned long long)width;

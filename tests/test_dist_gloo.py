@@ -89,11 +89,20 @@ class _OracleSlot:
     def __init__(self, scene, W, H):
         self.scene, self.W, self.H = scene, W, H
         self.objects = None
-        self.rows = (0, 1, False)
-        self.plane_ptr = 0
+        self.rows, self.run = (0, 1, False), 1
+        self.plane_ptr = self.out_ptr = 0
 
     def set_rows(self, first, step, plane):
-        self.rows = (first, step, plane)
+        self.rows, self.run = (first, step, plane), 1
+
+    def set_tile_pattern(self, first, step, run, plane):
+        self.rows, self.run = (first, step, plane), run
+
+    def set_output(self, ptr):
+        self.out_ptr = ptr or 0
+
+    def sync(self):
+        pass
 
     def set_plane_output(self, ptr):
         self.plane_ptr = ptr
@@ -104,17 +113,41 @@ class _OracleSlot:
     def render_async(self):
         import ctypes as C
         first, step, plane = self.rows
-        assert plane and self.plane_ptr
         px, _, _ = oracle_ffi.render(self.scene, self.W, self.H, want_rgb=False, objects=self.objects)
-        frame = px["rgba"].view(np.uint32).reshape(self.H, self.W)
-        mine = rdist.extract_plane(frame, self.W, self.H, first, step)
-        C.memmove(self.plane_ptr, mine.ctypes.data, mine.nbytes)
+        tiles = rdist.pattern_tiles(self.H, first, step, self.run)
+        if plane:                                   # local tile order, 4 B/px
+            assert self.plane_ptr
+            frame = px["rgba"].view(np.uint32).reshape(self.H, self.W)
+            mine = np.zeros((len(tiles) * 8, self.W), dtype=np.uint32)
+            for k, t in enumerate(tiles):
+                rows = frame[t * 8:min(t * 8 + 8, self.H)]
+                mine[k * 8:k * 8 + len(rows)] = rows
+            C.memmove(self.plane_ptr, mine.ctypes.data, mine.nbytes)
+        elif self.out_ptr:                          # its tiles of the 16 B/px framebuffer, in place
+            fb = np.ctypeslib.as_array(C.cast(self.out_ptr, C.POINTER(C.c_uint8)), shape=(self.H, self.W * 16))
+            src = px.view(np.uint8).reshape(self.H, self.W * 16)
+            for t in tiles:
+                fb[t * 8:min(t * 8 + 8, self.H)] = src[t * 8:min(t * 8 + 8, self.H)]
 
     def scatter_colour_plane(self, planes_ptr, out_ptr, W, H, world, stride_words, stream=None):
         import ctypes as C
         planes = np.ctypeslib.as_array(C.cast(planes_ptr, C.POINTER(C.c_uint32)), shape=(world, stride_words))
         out = rdist.reassemble_planes(planes, W, H, world)
         C.memmove(out_ptr, out.ctypes.data, out.nbytes)
+
+    def scatter_helper_planes3(self, planes3_ptr, out_ptr, W, H, world, root_run, stride_bytes, stream=None):
+        import ctypes as C
+        from relativitypathtracer_amd.renderer import PIXEL_DTYPE
+        raw = np.ctypeslib.as_array(C.cast(planes3_ptr, C.POINTER(C.c_uint8)), shape=(world, stride_bytes))
+        fb = np.ctypeslib.as_array(C.cast(out_ptr, C.POINTER(C.c_uint8)), shape=(H * W * 16,)).view(PIXEL_DTYPE).reshape(H, W)
+        period = root_run + world - 1
+        for j in range(1, world):
+            words = rdist.unpack_plane3(raw[j]).reshape(-1, W)
+            for k, t in enumerate(rdist.pattern_tiles(H, root_run + j - 1, period, 1)):
+                for y in range(t * 8, min(t * 8 + 8, H)):
+                    fb["x"][y] = np.arange(W, dtype=np.float32)
+                    fb["y"][y] = np.float32(y)
+                    fb["rgba"][y] = words[k * 8 + y - t * 8].view(np.uint8).reshape(W, 4)
 
     def pack_colour_plane3(self, plane4_ptr, plane3_ptr, pixels, stream=None):
         import ctypes as C
@@ -130,7 +163,7 @@ class _OracleSlot:
         C.memmove(out_ptr, out.ctypes.data, out.nbytes)
 
 
-def _sharder_worker(rank, world, port, W, H, frames, snap_path, out_path, plane_bytes):
+def _sharder_worker(rank, world, port, W, H, frames, snap_path, out_path, plane_bytes, root_run=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -140,12 +173,16 @@ def _sharder_worker(rank, world, port, W, H, frames, snap_path, out_path, plane_
         scene = Scene.from_file("shadows")
         snaps = np.load(snap_path)                      # Object[] of every frame, computed once by the test
         slots = [_OracleSlot(scene, W, H) for _ in range(3)]
-        sharder = rdist.FrameSharder(slots, W, H, rank, world, device="cpu", plane_bytes=plane_bytes)
-        assert sharder.exchange and sharder.depth == 3
+        if root_run == "auto":                       # measure + agree, as bench.py does on a real node
+            root_run, info = rdist.calibrate_split(slots, snaps[0], W, H, rank, world, device="cpu", frames=3)
+            assert root_run in (0, 1, 2, 4, 8, 16) and info["frame_ms_one_rank"] > 0
+        sharder = rdist.FrameSharder(slots, W, H, rank, world, device="cpu", plane_bytes=plane_bytes, root_run=root_run)
+        assert sharder.depth == 3 and (sharder.exchange or sharder.solo)
         seen = []
         for f in range(frames):
             sharder.render_and_gather(snaps[f])
             if rank == 0:                               # without streams the root reassembles at once
+                assert sharder.framebuffer is not None
                 seen.append(sharder.framebuffer.numpy().view(np.uint8).reshape(H * W, 16)[:, 8:12].copy().view(np.uint32)[:, 0])
         for s in sharder.slots:
             if s.work is not None:
@@ -165,11 +202,13 @@ def test_three_byte_plane_round_trip():
     assert np.array_equal(rdist.unpack_plane3(packed), words)
 
 
-@pytest.mark.parametrize("world,plane_bytes", [(2, 3), (3, 3), (2, 4)])
-def test_frame_sharder_three_frames_in_flight(tmp_path, world, plane_bytes):
+@pytest.mark.parametrize("world,plane_bytes,root_run", [(2, 3, None), (3, 3, None), (2, 4, None), (2, 3, 4), (3, 3, 2), (3, 3, 1), (2, 3, 0), (2, 3, "auto")])
+def test_frame_sharder_three_frames_in_flight(tmp_path, world, plane_bytes, root_run):
     """dist.FrameSharder itself, world 2 and 3 over gloo: three frame slots rotating over seven different frames
     (camera clock running), one gather per frame — of 3-byte planes (the default) or of the 4-byte planes as rendered;
-    rank 0's framebuffer after every frame must be that frame."""
+    with the equal split (root_run None), the weighted split (rank 0 renders root_run of every root_run + N - 1 tiles in
+    place), rank 0 alone (0), and the split measured and agreed on by calibrate_split ("auto").  Rank 0's framebuffer
+    after every frame must be that frame."""
     from relativitypathtracer_amd import Scene
     W, H, frames = 64, 77, 7
     scene = Scene.from_file("shadows")
@@ -185,7 +224,7 @@ def test_frame_sharder_three_frames_in_flight(tmp_path, world, plane_bytes):
     assert any(not np.array_equal(want[0], w) for w in want[1:])
     sp, op = str(tmp_path / "snaps.npy"), str(tmp_path / "out.npy")
     np.save(sp, np.stack(snaps))
-    mp.spawn(_sharder_worker, args=(world, _free_port(), W, H, frames, sp, op, plane_bytes), nprocs=world, join=True)
+    mp.spawn(_sharder_worker, args=(world, _free_port(), W, H, frames, sp, op, plane_bytes, root_run), nprocs=world, join=True)
     got = np.load(op)
     for f in range(frames):
         assert np.array_equal(got[f], want[f]), f"frame {f}"

@@ -409,7 +409,8 @@ def test_hip_frame_against_the_reference_screenshots(renderer, shot):
         assert (d > 2).mean() < 5e-4
 
 
-def test_bench_exchange_path_over_rccl_with_one_rank(tmp_path):
+@pytest.mark.parametrize("split", ["equal", "4", "auto"])
+def test_bench_exchange_path_over_rccl_with_one_rank(tmp_path, split):
     """bench.py's N > 1 frame path — colour planes, ONE RCCL gather per frame, root reassembly, three frames in
     flight — run as a real torch.distributed job of one rank (RPT_FORCE_DIST), camera clock running so that every
     frame differs; its own --check compares the root's last framebuffer with the oracle."""
@@ -422,7 +423,7 @@ def test_bench_exchange_path_over_rccl_with_one_rank(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = {**os.environ, "RPT_FORCE_DIST": "1", "RPT_BENCH_ANIMATE": "1"}
+    env = {**os.environ, "RPT_FORCE_DIST": "1", "RPT_BENCH_ANIMATE": "1", "RPT_SPLIT": split}   # "4": the weighted split's root path
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "14", "--warmup", "2",
            "--workload", "shadows", "--width", "1280", "--height", "720", "--no-cpu-baseline", "--check"]
@@ -432,6 +433,9 @@ def test_bench_exchange_path_over_rccl_with_one_rank(tmp_path):
     out = json.loads(line)
     assert out["check"] == "framebuffer rows identical to the oracle", out["check"]
     assert out["config"]["frames_in_flight"] == 3 and out["n_gpus"] == 1
+    if split == "auto":      # calibrate_split ran its gathers, barrier and broadcast over RCCL
+        cal = out["config"]["split_calibration"]
+        assert cal["frame_ms_one_rank"] > 0 and cal["gather_base_ms"] >= 0
 
 
 def test_16k_frame_structure_and_sampled_rows(renderer):
