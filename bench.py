@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("RPT_FRAMES_IN_FLIGHT", "3")),
                     help="frames in flight (contexts on concurrent streams); 1 = one frame at a time, as the reference's runKernel()")
+    ap.add_argument("--frames-per-exchange", type=int, default=int(os.environ.get("RPT_FRAMES_PER_EXCHANGE", "4")),
+                    help="N>1: frames whose planes travel in ONE gather (a collective costs as much host and launch time as a frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="after timing, compare rank 0's framebuffer with the oracle on a few row bands")
     ap.add_argument("--gather", default=os.environ.get("RPT_GATHER", "plane3"), choices=["plane3", "plane4"],
@@ -172,13 +174,14 @@ def main():
     split, split_info, root_run = os.environ.get("RPT_SPLIT", "auto"), None, None
     if (n > 1 or force_dist) and pipeline and args.gather == "plane3" and split != "equal":
         if split == "auto":
-            root_run, split_info = rdist.calibrate_split(renderers, scene, W, H, rank, n)
+            root_run, split_info = rdist.calibrate_split(renderers, scene, W, H, rank, n, frames_per_exchange=args.frames_per_exchange)
             if n == 1:
                 root_run = None              # one-rank rehearsal: the measurement ran, there is nothing to split
         else:
             root_run = 0 if split == "solo" else int(split)
     frame = rdist.FrameSharder(renderers, W, H, rank, n, force_gather=force_dist, pipeline=pipeline,
-                               plane_bytes=3 if args.gather == "plane3" else 4, root_run=root_run)   # allocates outputs; N == 1 renders straight into the framebuffers
+                               plane_bytes=3 if args.gather == "plane3" else 4, root_run=root_run,
+                               frames_per_exchange=args.frames_per_exchange)   # allocates outputs; N == 1 renders straight into the framebuffers
 
     animate = os.environ.get("RPT_BENCH_ANIMATE") == "1"     # rehearsal only: every frame differs (camera clock runs)
     clock = [t]
@@ -192,6 +195,7 @@ def main():
         frame.render_and_gather(scene)
 
     def barrier():
+        frame.flush()                   # a partial last batch of planes goes out now (every rank calls this at the same point)
         torch.cuda.synchronize()
         if n > 1:
             td.barrier()
@@ -274,7 +278,7 @@ def main():
             "config": {"workload": f"Scenes/{scene_name}.txt {W}x{H}, camera v={list(vel)} t={t}, interval={scene.params['interval']}, "
                                    f"mesh=Models/bunny.obj (StanfordBunny.obj is missing from the reference)" if scene_name == "bunny"
                        else f"Scenes/{scene_name}.txt {W}x{H}, camera v={list(vel)} t={t}",
-                       "frame": "rpt_set_objects + render kernel" + (f" + RCCL gather({frame.plane_bytes} B/px plane) + root scatter" if n > 1 else ""),
+                       "frame": "rpt_set_objects + render kernel" + (f" + RCCL gather({frame.plane_bytes} B/px planes, {frame.group} frames per gather) + root scatter" if n > 1 else ""),
                        "frames_in_flight": frame.depth,
                        "sharding": ("none" if n == 1 else "interleaved 8-row tiles, tile k -> rank k mod N" if root_run is None else
                                     "rank 0 renders the whole frame (the exchange would cost more than it saves)" if root_run == 0 else

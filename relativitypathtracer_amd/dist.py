@@ -57,7 +57,7 @@ def weighted_helper_words(width: int, height: int, world: int, root_run: int) ->
 
 
 def choose_root_run(frame_s: float, gather_base_s: float, gather_s_per_byte: float, width: int, height: int, world: int,
-                    overhead_s: float = 0.0) -> int:
+                    overhead_s: float = 0.0, frames_per_exchange: int = 1) -> int:
     """The split that minimises the modelled frame time of a pipelined N-rank job, from three measured numbers:
     `frame_s` (one rank rendering the WHOLE frame, frames in flight), and the exchange's linear cost model
     gather(b bytes per rank) = gather_base_s + gather_s_per_byte * b.  Candidates: the root renders everything and
@@ -68,7 +68,8 @@ def choose_root_run(frame_s: float, gather_base_s: float, gather_s_per_byte: flo
     for run in (1, 2, 4, 8, 16):
         period = run + world - 1
         share_root, share_helper = run / period, 1.0 / period
-        wire = gather_base_s + gather_s_per_byte * 3 * weighted_helper_words(width, height, world, run)
+        # one gather carries frames_per_exchange planes: its fixed cost is shared, its bytes are not
+        wire = gather_base_s / max(frames_per_exchange, 1) + gather_s_per_byte * 3 * weighted_helper_words(width, height, world, run)
         t = max(frame_s * share_root + overhead_s, frame_s * share_helper + overhead_s, wire)
         if t < best_t * 0.97:            # a split must clearly beat the simpler arrangement before it
             best, best_t = run, t
@@ -123,7 +124,8 @@ def reassemble_planes(planes: np.ndarray, width: int, height: int, world: int) -
     return out
 
 
-def calibrate_split(renderers, objects, width: int, height: int, rank: int, world: int, device=None, frames: int = 30):
+def calibrate_split(renderers, objects, width: int, height: int, rank: int, world: int, device=None, frames: int = 30,
+                    frames_per_exchange: int = 1):
     """Measure what choose_root_run needs and agree on the split: every rank renders the whole frame `frames` times
     with len(renderers) frames in flight (rank 0's time counts), all ranks time gathers of the smallest and the
     largest helper plane (a linear cost model of the exchange on THIS node's links), rank 0 picks the split and
@@ -177,7 +179,7 @@ def calibrate_split(renderers, objects, width: int, height: int, rank: int, worl
     base = max(t_small - per_byte * b_small, 0.0)
     choice = torch.zeros(1, dtype=torch.int32, device=dev)
     if rank == 0:
-        choice[0] = choose_root_run(frame_s, base, per_byte, width, height, world)
+        choice[0] = choose_root_run(frame_s, base, per_byte, width, height, world, frames_per_exchange=frames_per_exchange)
     td.broadcast(choice, src=0)
     sync()
     return int(choice[0]), {"frame_ms_one_rank": round(frame_s * 1e3, 4), "gather_base_ms": round(base * 1e3, 4),
@@ -185,30 +187,39 @@ def calibrate_split(renderers, objects, width: int, height: int, rank: int, worl
 
 
 class _Slot:
-    """One frame in flight: a context (rpt_ctx) on its own stream with its own output buffers."""
-    __slots__ = ("r", "stream", "framebuffer", "plane", "plane3", "gathered", "work", "scattered", "frames")
+    """One frame being rendered: a context (rpt_ctx) on its own stream with its render target."""
+    __slots__ = ("r", "stream", "framebuffer", "plane", "frames")
+
+
+class _Batch:
+    """The frames of one exchange: send / receive buffers, the root's framebuffers, and the events that order them."""
+    __slots__ = ("send", "recv", "fbs", "ready", "work", "done", "count")
 
 
 class FrameSharder:
-    """Owns the output tensors of one rank and runs render (+ gather + scatter) frame after frame.
+    """Owns the output tensors of one rank and runs render (+ exchange + reassembly) frame after frame.
 
     Frames in flight.  A frame's critical path is the serial octree walk of its dearest pixel, so
     one frame alone leaves most of the GPU idle for most of its duration.  The sharder therefore keeps
     ``len(renderers)`` frames in flight: every slot is a context of its own (scene resident once per context) on
-    its own stream with its own output buffers, frame f runs in slot ``f mod depth``, and kernels of consecutive
+    its own stream with its own render target, frame f runs in slot ``f mod depth``, and kernels of consecutive
     frames overlap on the device.  Each frame still gets its own ``rpt_set_objects`` (the host may change
     ``Object[]`` between any two frames) and is rendered completely; ``framebuffer`` is the last submitted frame.
 
-    With more than one rank the three stages of a frame run on different queues — render on the slot's
-    stream, the gather on RCCL's stream, the root's reassembly on a side stream — with per-slot planes.
-    Per frame every rank still issues exactly one collective, in the same order on all ranks; the host
-    never blocks (buffer reuse is ordered by stream-level waits only).
+    With more than one rank the exchange is ONE gather (RCCL over xGMI) per `frames_per_exchange` frames: a
+    collective costs tens of microseconds of host and launch time however small it is — as much as a frame — so
+    the planes of consecutive frames travel together.  Rendering, the exchange and the root's reassembly run on
+    different queues (the slots' streams, an exchange stream, a side stream) over two alternating batches of
+    buffers; the host never blocks (buffer reuse is ordered by events).  Every rank issues the same collectives in
+    the same order; ``flush()`` sends a partial last batch and must be called (by every rank) before the
+    framebuffer is read or a timed region ends.
     """
 
     def __init__(self, renderers, width: int, height: int, rank: int, world: int, force_gather: bool = False,
-                 pipeline: bool = True, device=None, plane_bytes: int = 3, root_run: Optional[int] = None):
+                 pipeline: bool = True, device=None, plane_bytes: int = 3, root_run: Optional[int] = None,
+                 frames_per_exchange: int = 4):
         """`device`: where the output tensors live; default the current GPU.  A CPU device (tests/test_dist_gloo.py:
-        gloo, stand-in renderers) runs the same slot rotation and exchange without streams.
+        gloo, stand-in renderers) runs the same rotation and exchange without streams.
         `plane_bytes`: bytes per pixel on the wire — 3 (default: the alpha byte of a packed colour is the constant
         1, so a small kernel drops it before the gather) or 4 (the rendered plane as it is).
         `root_run`: None = equal interleaved split (tile k -> rank k mod N, every plane gathered).  A power of two =
@@ -216,95 +227,99 @@ class FrameSharder:
         framebuffer and rank j the single tile root_run + j - 1 into a 3 B/px plane — pixels rendered where they are
         needed cross no link, so the root takes the larger share (choose_root_run sizes it).  0 = rank 0 renders the
         whole frame and nothing is exchanged (the other ranks idle): the arrangement to fall back to when the
-        exchange is slower than rendering."""
+        exchange is slower than rendering.
+        `pipeline` False: one slot, one frame per exchange, every stage waited for."""
         import torch
         if not isinstance(renderers, (list, tuple)):
             renderers = [renderers]
         if not pipeline:
-            renderers = renderers[:1]
+            renderers, frames_per_exchange = renderers[:1], 1
         self.W, self.H, self.rank, self.world = width, height, rank, world
         dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-        self.on_gpu = dev.type == "cuda"
-        self.local_rows = local_tile_count(height, rank, world) * TILE_ROWS
+        self.dev, self.on_gpu = dev, dev.type == "cuda"
         self.exchange = world > 1 or force_gather      # force_gather: run the plane/gather/scatter path with one rank
         self.root_run = root_run if ((world > 1 or force_gather) and root_run is not None) else None
         self.solo = self.root_run == 0                  # rank 0 renders everything, no exchange
         self.weighted = bool(self.root_run)
         if self.solo:
             self.exchange = False
-        self.depth = len(renderers)
-        assert plane_bytes in (3, 4)
-        self.plane_bytes = plane_bytes
-        self.pipeline = pipeline
-        self.frame = 0
-        self.last = None
-        self.slots = []
-        words = plane_words(width, height, world)
+        assert plane_bytes in (3, 4) and not (self.weighted and plane_bytes != 3), "the weighted split exchanges 3-byte planes"
+        self.plane_bytes, self.pipeline, self.depth = plane_bytes, pipeline, len(renderers)
+        self.group = max(1, int(frames_per_exchange)) if self.exchange else 1
+        self.frame, self.last, self.last_fb = 0, None, None
+
+        # which tiles this rank renders, how large a plane is
         if self.weighted:
-            assert plane_bytes == 3, "the weighted split exchanges 3-byte planes"
-            words = weighted_helper_words(width, height, world, self.root_run)
             period = self.root_run + world - 1
+            self.words = weighted_helper_words(width, height, world, self.root_run)
             mine = pattern_tiles(height, 0, period, self.root_run) if rank == 0 else pattern_tiles(height, self.root_run + rank - 1, period, 1)
             self.local_rows = len(mine) * TILE_ROWS
+        else:
+            self.words = plane_words(width, height, world)
+            self.local_rows = local_tile_count(height, rank, world) * TILE_ROWS
         if self.solo:
             self.local_rows = tile_count(height) * TILE_ROWS if rank == 0 else 0
+        self.plane_unit = self.words * 3 if plane_bytes == 3 else self.words          # elements of one frame's plane on the wire
+        wire_dtype = torch.uint8 if plane_bytes == 3 else torch.int32
+        renders_plane = self.exchange and not (self.weighted and rank == 0)            # the weighted root renders in place
+
+        self.slots = []
         for r in renderers:
             s = _Slot()
-            s.r = r
-            # The render kernels, the tensors below and what RCCL synchronises with must share ONE real stream per
-            # slot.  torch's default stream has handle 0, which the C-ABI reads as "the context's own stream": never it.
+            s.r, s.frames, s.framebuffer, s.plane = r, 0, None, None
+            # The render kernels and the tensors they touch share ONE real stream per slot.  torch's default stream has
+            # handle 0, which the C-ABI reads as "the context's own stream": never it.
             s.stream = torch.cuda.Stream(device=dev) if self.on_gpu else None
             if self.on_gpu:
                 r.set_stream(s.stream.cuda_stream)
-            s.framebuffer = s.plane = s.plane3 = s.gathered = s.work = s.scattered = None
-            s.frames = 0                         # frames submitted to this slot
             if not self.exchange:
                 r.set_rows(0, 1, False)
                 if not (self.solo and rank != 0):
                     s.framebuffer = torch.zeros(width * height * 4, dtype=torch.int32, device=dev)
                     r.set_output(s.framebuffer.data_ptr())
             elif self.weighted:
-                s.plane3 = torch.zeros(words * 3, dtype=torch.uint8, device=dev)       # send buffer (the root's is never read)
                 if rank == 0:
                     r.set_tile_pattern(0, period, self.root_run, False)
-                    s.framebuffer = torch.zeros(width * height * 4, dtype=torch.int32, device=dev)
-                    r.set_output(s.framebuffer.data_ptr())
-                    s.gathered = torch.zeros((world, words * 3), dtype=torch.uint8, device=dev)
                 else:
                     r.set_tile_pattern(self.root_run + rank - 1, period, 1, True)
-                    s.plane = torch.zeros(words, dtype=torch.int32, device=dev)
-                    r.set_plane_output(s.plane.data_ptr())
             else:
                 r.set_rows(rank, world, True)
-                s.plane = torch.zeros(words, dtype=torch.int32, device=dev)
+            if renders_plane:
+                s.plane = torch.zeros(self.words, dtype=torch.int32, device=dev)
                 r.set_plane_output(s.plane.data_ptr())
-                if plane_bytes == 3:
-                    s.plane3 = torch.zeros(words * 3, dtype=torch.uint8, device=dev)
-                if rank == 0:
-                    s.gathered = (torch.zeros((world, words), dtype=torch.int32, device=dev) if plane_bytes == 4 else
-                                  torch.zeros((world, words * 3), dtype=torch.uint8, device=dev))
             self.slots.append(s)
         self.r = self.slots[0].r
-        self._root_fb = None
-        self.side = None
-        if self.exchange and rank == 0:
-            if not self.weighted:
-                self._root_fb = torch.zeros(width * height * 4, dtype=torch.int32, device=dev)
-            self.side = torch.cuda.Stream(device=dev) if (pipeline and self.on_gpu) else None
+
+        self.batches = []
+        self.xstream = self.side = None
+        if self.exchange:
+            for _ in range(2 if pipeline else 1):
+                b = _Batch()
+                b.send = torch.zeros(self.group * self.plane_unit, dtype=wire_dtype, device=dev)
+                b.recv = torch.zeros((world, self.group * self.plane_unit), dtype=wire_dtype, device=dev) if rank == 0 else None
+                b.fbs = [torch.zeros(width * height * 4, dtype=torch.int32, device=dev) for _ in range(self.group)] if rank == 0 else None
+                b.ready = [torch.cuda.Event() for _ in range(self.group)] if self.on_gpu else None
+                b.done = torch.cuda.Event() if self.on_gpu else None
+                b.work, b.count = None, 0
+                self.batches.append(b)
+            if self.on_gpu:
+                self.xstream = torch.cuda.Stream(device=dev)
+                self.side = torch.cuda.Stream(device=dev) if rank == 0 else None
         if self.on_gpu:
             torch.cuda.synchronize(dev)     # the zero fills above ran on torch's stream; the slots launch on their own
 
     @property
     def framebuffer(self):
-        """Device tensor holding the most recently submitted frame (16 B/pixel); complete after a device sync."""
-        if self.exchange and not self.weighted:
-            return self._root_fb
+        """Tensor holding the most recently submitted frame (16 B/pixel) on rank 0; complete after flush() + a device sync."""
+        if self.exchange:
+            return self.last_fb
         return (self.last or self.slots[0]).framebuffer
 
     def render_and_gather(self, objects=None):
-        """Submit one frame: Object[] refresh (if given: a Scene or raw bytes), render, and with N > 1 the exchange."""
-        import torch
+        """Submit one frame: Object[] refresh (if given: a Scene or raw bytes), render, and with N > 1 its part of the
+        exchange (the gather itself goes out with the last frame of a batch, or with flush())."""
         slot = self.slots[self.frame % self.depth]
+        f = self.frame
         self.frame += 1
         slot.frames += 1
         self.last = slot
@@ -315,73 +330,83 @@ class FrameSharder:
                 slot.r.set_objects(objects)
             slot.r.render_async()
             return
-        if not self.on_gpu:
-            if objects is not None:
-                slot.r.set_objects(objects)
-            self._render_and_gather(slot)
-            return
-        with torch.cuda.stream(slot.stream):
-            if objects is not None:
-                slot.r.set_objects(objects)
-            self._render_and_gather(slot)
-
-    def _render_and_gather(self, slot):
-        import torch
-        import torch.distributed as td
-        if slot.work is not None:
-            slot.work.wait()                        # stream-level on the GPU: this slot's plane has left the device
-        if self.rank == 0 and slot.scattered is not None:
-            torch.cuda.current_stream().wait_event(slot.scattered)   # this slot's gather buffer has been consumed by the reassembly
-        slot.r.render_async()
-        if self.weighted:
-            self._exchange_weighted(slot)
-            return
-        send = slot.plane
-        if self.plane_bytes == 3:                   # drop the constant alpha byte: 3/4 of the bytes on the wire
-            slot.r.pack_colour_plane3(slot.plane.data_ptr(), slot.plane3.data_ptr(), slot.plane.numel(),
-                                      stream=slot.stream.cuda_stream if self.on_gpu else None)
-            send = slot.plane3
-        glist = list(slot.gathered.unbind(0)) if self.rank == 0 else None
-        work = td.gather(send, glist, dst=0, async_op=True)      # the one exchange step of the frame
-        slot.work = work
-        scatter = slot.r.scatter_colour_plane if self.plane_bytes == 4 else slot.r.scatter_colour_plane3
-        if self.rank == 0:
-            if self.side is None:
-                work.wait()
-                scatter(slot.gathered.data_ptr(), self._root_fb.data_ptr(), self.W, self.H, self.world, slot.gathered.shape[1])
-            else:
-                with torch.cuda.stream(self.side):
-                    work.wait()
-                    scatter(slot.gathered.data_ptr(), self._root_fb.data_ptr(), self.W, self.H, self.world,
-                            slot.gathered.shape[1], stream=self.side.cuda_stream)
-                    ev = torch.cuda.Event()
-                    ev.record(self.side)
-                    slot.scattered = ev
-        elif not self.pipeline:
-            work.wait()
-
-    def _exchange_weighted(self, slot):
-        """Helpers: pack and send their plane.  Root: its own tiles are already in the slot's framebuffer; receive the
-        helpers' planes and write their tiles into it."""
-        import torch
-        import torch.distributed as td
+        batch = self.batches[(f // self.group) % len(self.batches)]
+        k = f % self.group                     # position of the frame in its batch
         stream = slot.stream.cuda_stream if self.on_gpu else None
-        if self.rank != 0:
-            slot.r.pack_colour_plane3(slot.plane.data_ptr(), slot.plane3.data_ptr(), slot.plane.numel(), stream=stream)
-        glist = list(slot.gathered.unbind(0)) if self.rank == 0 else None
-        work = td.gather(slot.plane3, glist, dst=0, async_op=True)      # the one exchange step of the frame
-        slot.work = work
+        if self.on_gpu and batch.work is not None:
+            slot.stream.wait_event(batch.done)             # the batch's buffers are free again (exchange and reassembly over)
         if self.rank == 0:
-            args = (slot.gathered.data_ptr(), slot.framebuffer.data_ptr(), self.W, self.H, self.world, self.root_run, slot.gathered.shape[1])
-            if self.side is None:
-                work.wait()
-                slot.r.scatter_helper_planes3(*args)
+            self.last_fb = batch.fbs[k]
+        if objects is not None:
+            slot.r.set_objects(objects)
+        if self.weighted and self.rank == 0:
+            slot.r.set_output(batch.fbs[k].data_ptr())     # the root's own tiles go straight into this frame's framebuffer
+        slot.r.render_async()
+        if slot.plane is not None:                          # this rank's plane of the frame -> its place in the batch
+            unit = batch.send[k * self.plane_unit:(k + 1) * self.plane_unit]
+            if self.plane_bytes == 3:
+                slot.r.pack_colour_plane3(slot.plane.data_ptr(), unit.data_ptr(), self.words, stream=stream)
+            elif self.on_gpu:
+                import torch
+                with torch.cuda.stream(slot.stream):
+                    unit.copy_(slot.plane, non_blocking=True)
             else:
-                with torch.cuda.stream(self.side):
+                unit.copy_(slot.plane)
+        if self.on_gpu:
+            batch.ready[k].record(slot.stream)
+        batch.count = k + 1
+        if batch.count == self.group:
+            self._exchange(batch)
+
+    def flush(self):
+        """Send a partial last batch.  Every rank must call it at the same point (it may issue a collective)."""
+        if not self.exchange or self.frame == 0:
+            return
+        batch = self.batches[((self.frame - 1) // self.group) % len(self.batches)]
+        if 0 < batch.count < self.group:
+            self._exchange(batch)
+
+    def _exchange(self, batch):
+        """ONE gather for the batch's frames, then (rank 0) the reassembly of each of them."""
+        import torch
+        import torch.distributed as td
+        n = batch.count
+        batch.count = 0
+        glist = list(batch.recv.unbind(0)) if self.rank == 0 else None
+        if self.on_gpu:
+            for k in range(n):
+                self.xstream.wait_event(batch.ready[k])
+            with torch.cuda.stream(self.xstream):
+                work = td.gather(batch.send, glist, dst=0, async_op=True)      # the exchange step of these frames
+                if self.rank != 0:
                     work.wait()
-                    slot.r.scatter_helper_planes3(*args, stream=self.side.cuda_stream)
-                    ev = torch.cuda.Event()
-                    ev.record(self.side)
-                    slot.scattered = ev
-        elif not self.pipeline:
+                    batch.done.record(self.xstream)
+        else:
+            work = td.gather(batch.send, glist, dst=0, async_op=True)
             work.wait()
+        batch.work = work
+        if self.rank != 0:
+            return
+        side = self.side.cuda_stream if self.on_gpu else None
+
+        def reassemble():
+            for k in range(n):
+                src = batch.recv[:, k * self.plane_unit:(k + 1) * self.plane_unit]
+                # the k-th frame's planes lie (group * plane_unit) elements apart, one per rank
+                stride = batch.recv.shape[1] * batch.recv.element_size()
+                if self.weighted:
+                    self.r.scatter_helper_planes3(src.data_ptr(), batch.fbs[k].data_ptr(), self.W, self.H, self.world, self.root_run,
+                                                  stride, stream=side)
+                elif self.plane_bytes == 3:
+                    self.r.scatter_colour_plane3(src.data_ptr(), batch.fbs[k].data_ptr(), self.W, self.H, self.world, stride, stream=side)
+                else:
+                    self.r.scatter_colour_plane(src.data_ptr(), batch.fbs[k].data_ptr(), self.W, self.H, self.world, stride // 4, stream=side)
+        if self.on_gpu:
+            with torch.cuda.stream(self.side):
+                work.wait()
+                reassemble()
+                batch.done.record(self.side)
+            if not self.pipeline:
+                self.side.synchronize()
+        else:
+            reassemble()

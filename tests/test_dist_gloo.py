@@ -82,6 +82,13 @@ def test_sharded_frame_equals_single_frame(tmp_path, world):
     assert np.array_equal(np.load(op), frame)
 
 
+def _rank_rows(ptr, ctype, world, stride_elems, row_elems):
+    """View of `world` rows of row_elems elements that lie stride_elems apart, starting at ptr (no read past the last row)."""
+    import ctypes as C
+    flat = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=((world - 1) * stride_elems + row_elems,))
+    return np.lib.stride_tricks.as_strided(flat, shape=(world, row_elems), strides=(stride_elems * flat.itemsize, flat.itemsize))
+
+
 class _OracleSlot:
     """Stand-in for one frame slot's context on a machine without a GPU: the same calls dist.FrameSharder makes
     on a Renderer, answered by the CPU oracle and numpy (test infrastructure, like the oracle itself)."""
@@ -131,14 +138,14 @@ class _OracleSlot:
 
     def scatter_colour_plane(self, planes_ptr, out_ptr, W, H, world, stride_words, stream=None):
         import ctypes as C
-        planes = np.ctypeslib.as_array(C.cast(planes_ptr, C.POINTER(C.c_uint32)), shape=(world, stride_words))
-        out = rdist.reassemble_planes(planes, W, H, world)
+        planes = _rank_rows(planes_ptr, C.c_uint32, world, stride_words, rdist.plane_words(W, H, world))
+        out = rdist.reassemble_planes(np.ascontiguousarray(planes), W, H, world)
         C.memmove(out_ptr, out.ctypes.data, out.nbytes)
 
     def scatter_helper_planes3(self, planes3_ptr, out_ptr, W, H, world, root_run, stride_bytes, stream=None):
         import ctypes as C
         from relativitypathtracer_amd.renderer import PIXEL_DTYPE
-        raw = np.ctypeslib.as_array(C.cast(planes3_ptr, C.POINTER(C.c_uint8)), shape=(world, stride_bytes))
+        raw = _rank_rows(planes3_ptr, C.c_uint8, world, stride_bytes, 3 * rdist.weighted_helper_words(W, H, world, root_run))
         fb = np.ctypeslib.as_array(C.cast(out_ptr, C.POINTER(C.c_uint8)), shape=(H * W * 16,)).view(PIXEL_DTYPE).reshape(H, W)
         period = root_run + world - 1
         for j in range(1, world):
@@ -157,13 +164,13 @@ class _OracleSlot:
 
     def scatter_colour_plane3(self, planes3_ptr, out_ptr, W, H, world, stride_bytes, stream=None):
         import ctypes as C
-        raw = np.ctypeslib.as_array(C.cast(planes3_ptr, C.POINTER(C.c_uint8)), shape=(world, stride_bytes))
+        raw = _rank_rows(planes3_ptr, C.c_uint8, world, stride_bytes, 3 * rdist.plane_words(W, H, world))
         planes = np.stack([rdist.unpack_plane3(raw[r]) for r in range(world)])
         out = rdist.reassemble_planes(planes, W, H, world)
         C.memmove(out_ptr, out.ctypes.data, out.nbytes)
 
 
-def _sharder_worker(rank, world, port, W, H, frames, snap_path, out_path, plane_bytes, root_run=None):
+def _sharder_worker(rank, world, port, W, H, frames, snap_path, out_path, plane_bytes, root_run=None, group=3):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -176,20 +183,33 @@ def _sharder_worker(rank, world, port, W, H, frames, snap_path, out_path, plane_
         if root_run == "auto":                       # measure + agree, as bench.py does on a real node
             root_run, info = rdist.calibrate_split(slots, snaps[0], W, H, rank, world, device="cpu", frames=3)
             assert root_run in (0, 1, 2, 4, 8, 16) and info["frame_ms_one_rank"] > 0
-        sharder = rdist.FrameSharder(slots, W, H, rank, world, device="cpu", plane_bytes=plane_bytes, root_run=root_run)
+        sharder = rdist.FrameSharder(slots, W, H, rank, world, device="cpu", plane_bytes=plane_bytes, root_run=root_run,
+                                     frames_per_exchange=group)
         assert sharder.depth == 3 and (sharder.exchange or sharder.solo)
-        seen = []
+        seen = {}
+
+        def collect(first, count):                      # the frames of a batch that has just been exchanged
+            if rank != 0:
+                return
+            for f in range(first, first + count):
+                fb = sharder.slots[f % 3].framebuffer if sharder.solo else sharder.batches[(f // sharder.group) % 2].fbs[f % sharder.group]
+                seen[f] = fb.numpy().view(np.uint8).reshape(H * W, 16)[:, 8:12].copy().view(np.uint32)[:, 0]
+
         for f in range(frames):
             sharder.render_and_gather(snaps[f])
-            if rank == 0:                               # without streams the root reassembles at once
-                assert sharder.framebuffer is not None
-                seen.append(sharder.framebuffer.numpy().view(np.uint8).reshape(H * W, 16)[:, 8:12].copy().view(np.uint32)[:, 0])
-        for s in sharder.slots:
-            if s.work is not None:
-                s.work.wait()
+            if sharder.solo:
+                collect(f, 1)
+            elif (f + 1) % sharder.group == 0:          # without streams the root reassembles as soon as the batch is complete
+                collect(f + 1 - sharder.group, sharder.group)
+        sharder.flush()
+        if not sharder.solo and frames % sharder.group:
+            collect(frames - frames % sharder.group, frames % sharder.group)
         td.barrier()
         if rank == 0:
-            np.save(out_path, np.stack(seen))
+            assert sharder.framebuffer is not None
+            last = sharder.framebuffer.numpy().view(np.uint8).reshape(H * W, 16)[:, 8:12].copy().view(np.uint32)[:, 0]
+            assert np.array_equal(last, seen[frames - 1])
+            np.save(out_path, np.stack([seen[f] for f in range(frames)]))
     finally:
         td.destroy_process_group()
 
@@ -202,10 +222,12 @@ def test_three_byte_plane_round_trip():
     assert np.array_equal(rdist.unpack_plane3(packed), words)
 
 
-@pytest.mark.parametrize("world,plane_bytes,root_run", [(2, 3, None), (3, 3, None), (2, 4, None), (2, 3, 4), (3, 3, 2), (3, 3, 1), (2, 3, 0), (2, 3, "auto")])
-def test_frame_sharder_three_frames_in_flight(tmp_path, world, plane_bytes, root_run):
+@pytest.mark.parametrize("world,plane_bytes,root_run,group", [(2, 3, None, 3), (3, 3, None, 1), (2, 4, None, 2), (2, 3, 4, 4), (3, 3, 2, 3),
+                                                              (3, 3, 1, 2), (2, 3, 0, 3), (2, 3, "auto", 3)])
+def test_frame_sharder_three_frames_in_flight(tmp_path, world, plane_bytes, root_run, group):
     """dist.FrameSharder itself, world 2 and 3 over gloo: three frame slots rotating over seven different frames
-    (camera clock running), one gather per frame — of 3-byte planes (the default) or of the 4-byte planes as rendered;
+    (camera clock running), one gather per `group` frames (the last batch partial, sent by flush()) — of 3-byte
+    planes (the default) or of the 4-byte planes as rendered;
     with the equal split (root_run None), the weighted split (rank 0 renders root_run of every root_run + N - 1 tiles in
     place), rank 0 alone (0), and the split measured and agreed on by calibrate_split ("auto").  Rank 0's framebuffer
     after every frame must be that frame."""
@@ -224,7 +246,7 @@ def test_frame_sharder_three_frames_in_flight(tmp_path, world, plane_bytes, root
     assert any(not np.array_equal(want[0], w) for w in want[1:])
     sp, op = str(tmp_path / "snaps.npy"), str(tmp_path / "out.npy")
     np.save(sp, np.stack(snaps))
-    mp.spawn(_sharder_worker, args=(world, _free_port(), W, H, frames, sp, op, plane_bytes, root_run), nprocs=world, join=True)
+    mp.spawn(_sharder_worker, args=(world, _free_port(), W, H, frames, sp, op, plane_bytes, root_run, group), nprocs=world, join=True)
     got = np.load(op)
     for f in range(frames):
         assert np.array_equal(got[f], want[f]), f"frame {f}"
