@@ -170,7 +170,7 @@ class _OracleSlot:
         C.memmove(out_ptr, out.ctypes.data, out.nbytes)
 
 
-def _sharder_worker(rank, world, port, W, H, frames, snap_path, out_path, plane_bytes, root_run=None, group=3):
+def _sharder_worker(rank, world, port, W, H, frames, snap_path, out_path, plane_bytes, root_run=None, group=3, mid_flush=-1):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -201,6 +201,9 @@ def _sharder_worker(rank, world, port, W, H, frames, snap_path, out_path, plane_
                 collect(f, 1)
             elif (f + 1) % sharder.group == 0:          # without streams the root reassembles as soon as the batch is complete
                 collect(f + 1 - sharder.group, sharder.group)
+            elif f == mid_flush:                        # a flush in mid-batch (bench.py: between warm-up and the timed region)
+                sharder.flush()
+                collect(f - f % sharder.group, f % sharder.group + 1)
         sharder.flush()
         if not sharder.solo and frames % sharder.group:
             collect(frames - frames % sharder.group, frames % sharder.group)
@@ -223,7 +226,7 @@ def test_three_byte_plane_round_trip():
 
 
 @pytest.mark.parametrize("world,plane_bytes,root_run,group", [(2, 3, None, 3), (3, 3, None, 1), (2, 4, None, 2), (2, 3, 4, 4), (3, 3, 2, 3),
-                                                              (3, 3, 1, 2), (2, 3, 0, 3), (2, 3, "auto", 3)])
+                                                              (3, 3, 1, 2), (2, 3, 0, 3), (2, 3, "auto", 3), (2, 3, 2, 4)])
 def test_frame_sharder_three_frames_in_flight(tmp_path, world, plane_bytes, root_run, group):
     """dist.FrameSharder itself, world 2 and 3 over gloo: three frame slots rotating over seven different frames
     (camera clock running), one gather per `group` frames (the last batch partial, sent by flush()) — of 3-byte
@@ -246,7 +249,8 @@ def test_frame_sharder_three_frames_in_flight(tmp_path, world, plane_bytes, root
     assert any(not np.array_equal(want[0], w) for w in want[1:])
     sp, op = str(tmp_path / "snaps.npy"), str(tmp_path / "out.npy")
     np.save(sp, np.stack(snaps))
-    mp.spawn(_sharder_worker, args=(world, _free_port(), W, H, frames, sp, op, plane_bytes, root_run, group), nprocs=world, join=True)
+    mp.spawn(_sharder_worker, args=(world, _free_port(), W, H, frames, sp, op, plane_bytes, root_run, group, 4 if (root_run, group) == (2, 4) else -1),
+             nprocs=world, join=True)
     got = np.load(op)
     for f in range(frames):
         assert np.array_equal(got[f], want[f]), f"frame {f}"
