@@ -506,3 +506,86 @@ def test_weighted_split_reassembles_to_the_single_gpu_frame(renderer, world, roo
     renderer.set_rows(0, 1, False)
     renderer.set_plane_output(None)
     renderer.set_output(None)
+
+
+@pytest.mark.parametrize("world,root_run,group", [(2, 4, 4), (4, None, 2), (4, 8, 4), (3, 0, 4)])
+def test_frame_sharder_with_virtual_ranks_on_one_gpu(monkeypatch, world, root_run, group):
+    """dist.FrameSharder's GPU path (streams, events, batches, rpt_set_tile_pattern, pack, reassembly) for N > 1 with
+    all N ranks living in this process on this one GPU: torch.distributed.gather is replaced by device copies between
+    the ranks' buffers, everything else is the production code.  Eleven animated frames; rank 0's framebuffers of
+    the last two batches must be the oracle's frames."""
+    import torch
+    import torch.distributed as td
+    from relativitypathtracer_amd import Scene
+    from relativitypathtracer_amd.renderer import Renderer
+    W, H, frames = 640, 360, 11
+    scene = Scene.from_file("shadows")
+    scene.set_paused(False)
+    scene.set_camera((0, 0, 0), 14.0)
+    scene.update_objects()
+    state = {"rank": 0, "pending": {}}
+
+    class Work:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            if self.ev is not None:
+                torch.cuda.current_stream().wait_event(self.ev)
+
+    def fake_gather(tensor, gather_list=None, dst=0, async_op=False):
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        if state["rank"] != 0:                               # helpers call first; their planes wait for the root's call
+            state["pending"][state["rank"]] = (tensor, ev)
+            return Work(None)
+        gather_list[0].copy_(tensor, non_blocking=True)
+        for r, (t, e) in state["pending"].items():
+            cur.wait_event(e)
+            gather_list[r].copy_(t, non_blocking=True)
+        state["pending"].clear()
+        done = torch.cuda.Event()
+        done.record(cur)
+        return Work(done)
+
+    monkeypatch.setattr(td, "gather", fake_gather)
+    ranks = []
+    for rank in range(world):
+        rs = [Renderer(0) for _ in range(3)]
+        rs[0].upload_scene(scene)
+        for r in rs[1:]:
+            r.share_scene(rs[0])
+        for r in rs:
+            r.set_scene_params(scene, W, H)
+        ranks.append((rs, rdist.FrameSharder(rs, W, H, rank, world, root_run=root_run, frames_per_exchange=group)))
+    try:
+        snaps = []
+        for f in range(frames):
+            scene.advance_time(300)
+            scene.update_objects()
+            snaps.append(scene.buffers()["objects"].copy())
+            for rank in list(range(1, world)) + [0]:         # the root last: its gather call completes the exchange
+                state["rank"] = rank
+                ranks[rank][1].render_and_gather(scene)
+            torch.cuda.synchronize()
+        for rank in list(range(1, world)) + [0]:
+            state["rank"] = rank
+            ranks[rank][1].flush()
+        torch.cuda.synchronize()
+        root = ranks[0][1]
+        checked = 0
+        first = frames - 3 if root.solo else max(0, ((frames - 1) // root.group - 1) * root.group)   # what is still held: 3 slots / 2 batches
+        for f in range(first, frames):
+            fb = root.slots[f % 3].framebuffer if root.solo else root.batches[(f // root.group) % 2].fbs[f % root.group]
+            opx, _, _ = oracle_ffi.render(scene, W, H, want_rgb=False, objects=snaps[f])
+            got = fb.cpu().numpy().view(np.uint8).reshape(H * W, 16)[:, 8:12]
+            assert np.array_equal(got, opx["rgba"]), f"frame {f}"
+            checked += 1
+        assert checked >= 3
+        opx, _, _ = oracle_ffi.render(scene, W, H, want_rgb=False, objects=snaps[-1])
+        assert np.array_equal(root.framebuffer.cpu().numpy().view(np.uint8).reshape(H * W, 16)[:, 8:12], opx["rgba"])
+    finally:
+        for rs, _ in ranks:
+            for r in rs:
+                r.close()
