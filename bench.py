@@ -20,7 +20,12 @@ one at a time (the reference's blocking runKernel) are timed right after and rep
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (see the keys at the bottom of main()).
+Rank 0 prints ONE JSON line.  Beside the contract's keys: `kernel_ms` (mean HIP-event duration of a render launch in
+the timed region), `one_frame_at_a_time` (the same frames submitted and waited for one by one: latency), `roofline`
+(`achieved` from the launch duration and the number of launches sharing the device, `single_launch` without overlap,
+`traffic` from the committed rocprofv3 PMC passes), `cpu_baseline` (the oracle on this host's cores), `total_rays`
+(primary + shadow rays), `config.sharding` / `config.split_calibration` (N > 1: the arrangement chosen and the
+measurements it was chosen from), `check` (with --check: rank 0's framebuffer against the oracle).
 """
 from __future__ import annotations
 

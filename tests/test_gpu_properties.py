@@ -589,3 +589,20 @@ def test_frame_sharder_with_virtual_ranks_on_one_gpu(monkeypatch, world, root_ru
         for rs, _ in ranks:
             for r in rs:
                 r.close()
+
+
+def test_tile_pattern_arguments(renderer):
+    """rpt_set_tile_pattern rejects what the kernel's shift/mask tile arithmetic cannot express."""
+    from relativitypathtracer_amd.renderer import RenderError
+    for first, step, run in [(0, 4, 3), (0, 4, 8), (-1, 4, 1), (0, 0, 1), (0, 4, 0)]:
+        with pytest.raises(RenderError):
+            renderer.set_tile_pattern(first, step, run, False)
+    renderer.set_tile_pattern(0, 4, 4, False)          # the whole period: every tile
+    scene = load_config("cube")
+    _setup(renderer, scene, 64, 40)
+    renderer.set_tile_pattern(0, 4, 4, False)
+    renderer.set_output(None)
+    renderer.render()
+    opx, _, _ = oracle_ffi.render(scene, 64, 40, want_rgb=False)
+    assert np.array_equal(renderer.read_framebuffer()["rgba"], opx["rgba"])
+    renderer.set_rows(0, 1, False)
