@@ -8,7 +8,11 @@
 //
 //   hipcc -O2 -std=c++17 -Iinclude examples/rpt_multi_gpu_main.cpp -o rpt_multi_gpu \
 //       -Lrelativitypathtracer_amd -lrpt_hip -lrpt_scene -lrccl -Wl,-rpath,$PWD/relativitypathtracer_amd
-//   ./rpt_multi_gpu 3840 2160 out.ppm frames [n_gpus] < assets/reference/Scenes/shadows.txt
+//   ./rpt_multi_gpu 3840 2160 out.ppm frames [n_gpus [root_run]] < assets/reference/Scenes/shadows.txt
+//
+// root_run (a power of two) selects the WEIGHTED split: per period of root_run + N - 1 tiles GPU 0 renders root_run
+// tiles straight into the frame's framebuffer and GPU j the single tile root_run + j - 1 into its plane — pixels
+// rendered on GPU 0 cross no link (rpt_set_tile_pattern, rpt_scatter_helper_planes3_on).
 //
 // (bench.py does the same with one process per GPU over torch.distributed; this file is the drop-in shape for the
 // reference's single-process C++ host.)
@@ -37,7 +41,7 @@
 
 int main(int argc, char **argv) {
     if (argc < 5) {
-        std::fprintf(stderr, "usage: %s width height out.ppm frames [n_gpus] < scene.txt\n", argv[0]);
+        std::fprintf(stderr, "usage: %s width height out.ppm frames [n_gpus [root_run]] < scene.txt\n", argv[0]);
         return 2;
     }
     const int width = std::atoi(argv[1]), height = std::atoi(argv[2]), frames = std::atoi(argv[4]);
@@ -48,6 +52,8 @@ int main(int argc, char **argv) {
     }
     if (argc >= 6 && std::atoi(argv[5]) >= 1 && std::atoi(argv[5]) < n) n = std::atoi(argv[5]);
     const int kSlots = 3;
+    const int root_run = argc >= 7 ? std::atoi(argv[6]) : 0;      // 0: equal split, tile k -> GPU k mod N
+    const int period = root_run ? root_run + n - 1 : n;
 
     const std::string text((std::istreambuf_iterator<char>(std::cin)), std::istreambuf_iterator<char>());
     rpt_scene *scene = rpt_scene_create();
@@ -70,7 +76,7 @@ int main(int argc, char **argv) {
 
     // per GPU: three frame slots = three contexts on one resident scene, each with a stream and a colour plane
     const size_t tiles = (size_t)(height + RPT_TILE_ROWS - 1) / RPT_TILE_ROWS;
-    const size_t words = ((tiles + n - 1) / n) * RPT_TILE_ROWS * (size_t)width;        // padded: every GPU sends the same count
+    const size_t words = ((tiles + period - 1) / period) * RPT_TILE_ROWS * (size_t)width;   // padded: every GPU sends the same count
     std::vector<std::vector<rpt_ctx *>> ctx(n, std::vector<rpt_ctx *>(kSlots, nullptr));
     std::vector<std::vector<hipStream_t>> stream(n, std::vector<hipStream_t>(kSlots));
     std::vector<std::vector<void *>> plane(n, std::vector<void *>(kSlots, nullptr)), plane3 = plane;
@@ -82,13 +88,16 @@ int main(int argc, char **argv) {
             CHECK(rpt_create(&ctx[d][k], d));
             CHECK(k == 0 ? rpt_upload_scene(ctx[d][0], &desc) : rpt_share_scene(ctx[d][k], ctx[d][0]));
             CHECK(rpt_set_params(ctx[d][k], wp, ambient, width, height, interval));
-            CHECK(rpt_set_rows(ctx[d][k], d, n, /*colour_plane=*/1));
+            if (!root_run) CHECK(rpt_set_rows(ctx[d][k], d, n, /*colour_plane=*/1));
+            else if (d == 0) CHECK(rpt_set_tile_pattern(ctx[d][k], 0, period, root_run, /*colour_plane=*/0));
+            else CHECK(rpt_set_tile_pattern(ctx[d][k], root_run + d - 1, period, 1, /*colour_plane=*/1));
             CHECK(hipStreamCreateWithFlags(&stream[d][k], hipStreamNonBlocking));
             CHECK(rpt_set_stream(ctx[d][k], stream[d][k]));
             CHECK(hipMalloc(&plane[d][k], words * 4));
             CHECK(hipMemset(plane[d][k], 0, words * 4));
-            CHECK(rpt_set_plane_output(ctx[d][k], plane[d][k]));
+            if (!(root_run && d == 0)) CHECK(rpt_set_plane_output(ctx[d][k], plane[d][k]));
             CHECK(hipMalloc(&plane3[d][k], words * 3));
+            CHECK(hipMemset(plane3[d][k], 0, words * 3));
         }
     }
     std::vector<ncclComm_t> comm(n);
@@ -96,8 +105,11 @@ int main(int argc, char **argv) {
     CHECK(hipSetDevice(0));
     std::vector<void *> gathered(kSlots, nullptr);
     for (int k = 0; k < kSlots; k++) CHECK(hipMalloc(&gathered[k], (size_t)n * words * 3));
-    void *framebuffer = nullptr;
-    CHECK(hipMalloc(&framebuffer, (size_t)width * height * 16));
+    std::vector<void *> framebuffer(kSlots, nullptr);             // one per frame slot: a frame is complete in ITS buffer
+    for (int k = 0; k < kSlots; k++) {
+        CHECK(hipMalloc(&framebuffer[k], (size_t)width * height * 16));
+        if (root_run) CHECK(rpt_set_output(ctx[0][k], framebuffer[k]));     // GPU 0's own tiles are rendered in place
+    }
 
     const auto t0 = std::chrono::steady_clock::now();
     for (int f = 0; f < frames; f++) {
@@ -108,13 +120,14 @@ int main(int argc, char **argv) {
         for (int d = 0; d < n; d++) {
             CHECK(rpt_set_objects(ctx[d][k], desc.objects, (int)desc.object_count));      //      Render.cpp:202
             CHECK(rpt_render_async(ctx[d][k]));                                          // runKernel()
-            CHECK(rpt_pack_colour_plane3_on(ctx[d][k], stream[d][k], plane[d][k], plane3[d][k], words));
+            if (!(root_run && d == 0)) CHECK(rpt_pack_colour_plane3_on(ctx[d][k], stream[d][k], plane[d][k], plane3[d][k], words));
         }
         CHECK(ncclGroupStart());                                 // the frame's one exchange step
         for (int d = 0; d < n; d++)
             CHECK(ncclGather(plane3[d][k], gathered[k], words * 3, ncclUint8, 0, comm[d], stream[d][k]));
         CHECK(ncclGroupEnd());
-        CHECK(rpt_scatter_colour_plane3_on(ctx[0][k], stream[0][k], gathered[k], framebuffer, width, height, n, words * 3));
+        if (root_run) CHECK(rpt_scatter_helper_planes3_on(ctx[0][k], stream[0][k], gathered[k], framebuffer[k], width, height, n, root_run, words * 3));
+        else CHECK(rpt_scatter_colour_plane3_on(ctx[0][k], stream[0][k], gathered[k], framebuffer[k], width, height, n, words * 3));
     }
     for (int d = 0; d < n; d++)
         for (int k = 0; k < kSlots; k++) CHECK(rpt_sync(ctx[d][k]));
@@ -124,7 +137,7 @@ int main(int argc, char **argv) {
 
     std::vector<unsigned char> fb((size_t)width * height * 16);
     CHECK(hipSetDevice(0));
-    CHECK(hipMemcpy(fb.data(), framebuffer, fb.size(), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(fb.data(), framebuffer[(frames - 1) % kSlots], fb.size(), hipMemcpyDeviceToHost));
     const int rc = rpt_write_ppm(argv[3], fb.data(), width, height);                     // drawGL()   gl_interop.cpp:51
     for (int d = 0; d < n; d++) {
         ncclCommDestroy(comm[d]);

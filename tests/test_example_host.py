@@ -105,7 +105,8 @@ def test_multi_gpu_example_builds_and_fails_loudly_without_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-def test_multi_gpu_example_matches_oracle(tmp_path):
+@pytest.mark.parametrize("root_run", ["0", "4"])
+def test_multi_gpu_example_matches_oracle(tmp_path, root_run):
     """The native C++ multi-GPU host (row tiles -> colour planes -> ONE ncclGather -> root reassembly, three frames
     in flight) on the GPUs this box has (one: the gather is then GPU 0 to itself): 20 animated frames, the PPM
     holds the last."""
@@ -115,7 +116,7 @@ def test_multi_gpu_example_matches_oracle(tmp_path):
     out = tmp_path / "multi.ppm"
     W, H, frames = 320, 184, 20
     with open(os.path.join(ASSETS, "Scenes", "shadows.txt")) as f:
-        p = subprocess.run([exe, str(W), str(H), str(out), str(frames), "1"], stdin=f, capture_output=True, text=True,
+        p = subprocess.run([exe, str(W), str(H), str(out), str(frames), "1", root_run], stdin=f, capture_output=True, text=True,
                            env={**os.environ, "RPT_ASSETS": ASSETS, "RPT_T0": "16"}, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     assert f"{frames} frames of {W}x{H}, 3 in flight" in p.stderr
