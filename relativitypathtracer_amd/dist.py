@@ -70,7 +70,9 @@ def choose_root_run(frame_s: float, gather_base_s: float, gather_s_per_byte: flo
         share_root, share_helper = run / period, 1.0 / period
         # one gather carries frames_per_exchange planes: its fixed cost is shared, its bytes are not
         wire = gather_base_s / max(frames_per_exchange, 1) + gather_s_per_byte * 3 * weighted_helper_words(width, height, world, run)
-        t = max(frame_s * share_root + overhead_s, frame_s * share_helper + overhead_s, wire)
+        # the root also reassembles the helpers' tiles (3 B read + 16 B written per pixel, at a conservative 3 TB/s)
+        reassembly = 19.0 * width * height * (1.0 - share_root) / 3.0e12
+        t = max(frame_s * share_root + reassembly + overhead_s, frame_s * share_helper + overhead_s, wire)
         if t < best_t * 0.97:            # a split must clearly beat the simpler arrangement before it
             best, best_t = run, t
     return best
