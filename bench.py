@@ -179,9 +179,15 @@ def main():
     split, split_info, root_run = os.environ.get("RPT_SPLIT", "auto"), None, None
     if (n > 1 or force_dist) and pipeline and args.gather == "plane3" and split != "equal":
         if split == "auto":
-            root_run, split_info = rdist.calibrate_split(renderers, scene, W, H, rank, n, frames_per_exchange=args.frames_per_exchange)
+            # the cost model proposes a split; it, its neighbours and "rank 0 alone" are then tried for a few batches
+            # each and the fastest is kept (every rank sees the same max-over-ranks times, so all agree)
+            model_run, split_info = rdist.calibrate_split(renderers, scene, W, H, rank, n, frames_per_exchange=args.frames_per_exchange)
+            cands = sorted({0, model_run} | ({max(1, model_run // 2), min(16, model_run * 2)} if model_run else {4}))
+            root_run, tried = rdist.autotune_split(renderers, scene, W, H, rank, n, cands, frames_per_exchange=args.frames_per_exchange,
+                                                   force_gather=force_dist, rounds=6)
+            split_info = dict(split_info, model_choice=model_run, tried_ms_per_frame={str(c): round(v * 1e3, 4) for c, v in tried.items()})
             if n == 1:
-                root_run = None              # one-rank rehearsal: the measurement ran, there is nothing to split
+                root_run = None              # one-rank rehearsal: the measurements ran, there is nothing to split
         else:
             root_run = 0 if split == "solo" else int(split)
     frame = rdist.FrameSharder(renderers, W, H, rank, n, force_gather=force_dist, pipeline=pipeline,

@@ -188,6 +188,50 @@ def calibrate_split(renderers, objects, width: int, height: int, rank: int, worl
                             "gather_GBps_per_rank": round(1e-9 / per_byte, 2) if per_byte > 0 else None}
 
 
+def autotune_split(renderers, objects, width: int, height: int, rank: int, world: int, candidates, device=None,
+                   frames_per_exchange: int = 4, force_gather: bool = False, rounds: int = 3):
+    """Run each candidate arrangement (values of FrameSharder's root_run: 0 = rank 0 alone, a power of two = weighted)
+    for `rounds` batches of frames and keep the fastest.  A candidate's time is the MAX over ranks of the wall time
+    per frame (one all_reduce), so every rank holds the same numbers and picks the same arrangement; ties go to the
+    smaller root_run.  Collectives per candidate: what its frames need, one barrier, one all_reduce — the same on
+    every rank.  Returns (root_run, {candidate: seconds per frame})."""
+    import time
+    import torch
+    import torch.distributed as td
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
+    results = {}
+    for cand in candidates:
+        sharder = FrameSharder(renderers, width, height, rank, world, force_gather=force_gather, device=device, root_run=cand,
+                               frames_per_exchange=frames_per_exchange)
+        n = rounds * max(sharder.group, 1)
+        for _ in range(max(sharder.group, 1)):
+            sharder.render_and_gather(objects)
+        sharder.flush()
+        sync()
+        td.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            sharder.render_and_gather(objects)
+        sharder.flush()
+        for r in renderers:
+            r.sync()
+        sync()
+        t = torch.tensor([(time.perf_counter() - t0) / n], dtype=torch.float64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        results[cand] = float(t[0])
+        del sharder
+        if dev.type == "cuda":
+            torch.cuda.empty_cache()
+    best = min(results, key=lambda c: (results[c], c))
+    return best, results
+
+
 class _Slot:
     """One frame being rendered: a context (rpt_ctx) on its own stream with its render target."""
     __slots__ = ("r", "stream", "framebuffer", "plane", "frames")

@@ -181,8 +181,11 @@ def _sharder_worker(rank, world, port, W, H, frames, snap_path, out_path, plane_
         snaps = np.load(snap_path)                      # Object[] of every frame, computed once by the test
         slots = [_OracleSlot(scene, W, H) for _ in range(3)]
         if root_run == "auto":                       # measure + agree, as bench.py does on a real node
-            root_run, info = rdist.calibrate_split(slots, snaps[0], W, H, rank, world, device="cpu", frames=3)
-            assert root_run in (0, 1, 2, 4, 8, 16) and info["frame_ms_one_rank"] > 0
+            model_run, info = rdist.calibrate_split(slots, snaps[0], W, H, rank, world, device="cpu", frames=3)
+            assert model_run in (0, 1, 2, 4, 8, 16) and info["frame_ms_one_rank"] > 0
+            root_run, tried = rdist.autotune_split(slots, snaps[0], W, H, rank, world, sorted({0, 2, model_run}), device="cpu",
+                                                   frames_per_exchange=group, rounds=1)
+            assert root_run in tried and all(v > 0 for v in tried.values())
         sharder = rdist.FrameSharder(slots, W, H, rank, world, device="cpu", plane_bytes=plane_bytes, root_run=root_run,
                                      frames_per_exchange=group)
         assert sharder.depth == 3 and (sharder.exchange or sharder.solo)
