@@ -48,7 +48,15 @@ REFERENCE_SHOTS = {
     "cube2": dict(scene="cube", v=(math.tanh(7373 / 5000.0), 0.0, 0.0), t=0.0, interval=0),
     "cube3": dict(scene="cube", v=(math.tanh(7373 / 5000.0), 0.0, 0.0), t=4.174, interval=-1),
     "arch2": dict(scene="arch", v=(0.0, 0.0, math.tanh(9209.8 / 5000.0)), t=5.761, interval=-1),
+    # Scenes/shadows.txt (README.md:117-122): camera at rest, only the clock is unknown.  The pear is a mesh: these four
+    # pin the OBJ loader, the octree builder and the octree walk (primary and shadow rays) on the reference's output.
+    "shadows1": dict(scene="shadows", v=(0.0, 0.0, 0.0), t=6.157, interval=-1),
+    "shadows2": dict(scene="shadows", v=(0.0, 0.0, 0.0), t=9.212, interval=-1),
+    "shadows4": dict(scene="shadows", v=(0.0, 0.0, 0.0), t=18.229, interval=-1),
+    "shadows5": dict(scene="shadows", v=(0.0, 0.0, 0.0), t=25.987, interval=-1),
 }
+SHADOWS_CROP = (540, 980, 1200, 1720)     # y0, y1, x0, x1 of tests/golden/ref_shadows*_crop_y540_x1200.png (pear, its shadow, the light)
+SHADOWS_PEAR_OBJECT = 4                   # index of the mesh object in Scenes/shadows.txt
 # Frames of the reference's animated GIFs (camera at rest, objects at 0.9c): (scene, frame index, camera clock)
 REFERENCE_GIF_FRAMES = {
     "cubes": [("cubes", 26, 5.85)],                                                        # light propagation on

@@ -19,6 +19,13 @@ Results (kept in tests/conftest.py::REFERENCE_SHOTS; tests/test_oracle.py checks
   arch2.png  v = (0, 0, tanh(9209.8/5000)) = 0.9509829 c, t = 5.761 s, light propagation on
              4 pixels off by > 1 LSB (36 760 by exactly 1); 0 of 163 840 in the brick band used for the search,
              1 350 / 650 one tenth of a rapidity step away, ~18 000 one millisecond away
+  shadows1.png, shadows2.png, shadows4.png, shadows5.png (Scenes/shadows.txt, README.md:117-122: camera at rest, light
+             propagation on, a light sphere crossing the scene at 0.95c; the pear is a MESH, so these are the grabs
+             that reach the OBJ loader, the octree builder and the octree walk for primary and shadow rays)
+             only the clock is unknown: t = 6.157 s, 9.212 s, 18.229 s, 25.987 s ->
+             24 / 31 / 33 / 55 of 3 525 120 pixels off by > 1 LSB (105 / 93 / 218 / 1 761 differ at all);
+             one millisecond earlier or later 47..79 / 248..297 / 95..97 / 92..124, three away 264 / 840 / 298 / 322.
+             Of the pear's own 34 099 pixels, 0 / 0 / 1 / 0 are off by > 1 LSB and 0 / 1 / 25 / 47 differ at all.
 The residual pixels of the cube grabs are crate-texture texels (the reference decodes box.jpg with CImg/libjpeg,
 the harness with Pillow) and silhouette pixels, as for the static cube1.png.
 """
@@ -77,3 +84,8 @@ if __name__ == "__main__":
     search("cube", "cube2", 0, 0, range(73600, 73860, 10), [0], (826, 1377))
     search("cube", "cube3", 0, -1, [73730], range(4164, 4185), (826, 1377))
     search("arch", "arch2", 2, -1, range(92080, 92120), range(5759, 5764), (1000, 1064))
+    # Scenes/shadows.txt: camera at rest, clock only.  Coarse stage: 25 ms steps over 0..30 s on the lit floor band
+    # (rows 850..1000), then every millisecond around the best, then the whole frame.
+    for shot in ("shadows1", "shadows2", "shadows4", "shadows5"):
+        coarse = search("shadows", shot, 0, -1, [0], range(0, 30000, 25), (850, 1000))
+        search("shadows", shot, 0, -1, [0], range(coarse[2] - 30, coarse[2] + 31), (0, H))

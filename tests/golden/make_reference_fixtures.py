@@ -22,6 +22,14 @@ bar; the client area is 2560x1377.
                          values (tests/conftest.py::REFERENCE_GIF_FRAMES) were found like the grabs' — and come out
                          40 ms per frame apart for the ladder, the GIF's own frame time.
 
+  shadows1/2/4/5.png     Scenes/shadows.txt (README.md:117-122) from a camera at rest with light propagation on: a light
+                         sphere crossing the scene at 0.95c, two cubes, a sphere and the pear MESH (Models/pear.obj through
+                         the OBJ loader, the octree builder and intersect_octree / intersect_triangle / intersect_AABB /
+                         getOppositeBoxSide — opencl_kernel.cl:106-308 — for primary AND shadow rays).  The only unknown of
+                         these grabs is the camera clock (whole milliseconds); tests/golden/fit_reference_camera.py
+                         finds 6.157 s, 9.212 s, 18.229 s and 25.987 s.  The crop holds the pear, the part of its shadow
+                         next to it and (shadows4/5) the light.
+
 Written per image: an exact stride-4 subsample of the client area (every 4th pixel of every 4th row, no
 filtering) and one full-resolution crop of the part with the most detail.
 """
@@ -40,6 +48,10 @@ CROPS = {
     "cube2": (826, 1377, 1150, 1410),    # the length-contracted crate
     "cube3": (826, 1377, 1000, 1620),    # the crate as seen with light delay (Terrell rotation)
     "arch2": (900, 1300, 960, 1600),     # brick floor under the arch: the most position-sensitive texture
+    "shadows1": (540, 980, 1200, 1720),  # the pear (mesh path), dimly lit from the left
+    "shadows2": (540, 980, 1200, 1720),
+    "shadows4": (540, 980, 1200, 1720),  # the pear lit from the right, its shadow on the wall, the light sphere
+    "shadows5": (540, 980, 1200, 1720),
 }
 
 for name, crop in CROPS.items():

@@ -45,7 +45,7 @@ def test_against_committed_golden_frames(renderer, name):
     assert np.array_equal(rgb.view(np.uint32), g["rgb"].view(np.uint32))
 
 
-FULL = [("bunny", 3840, 2160), ("shadows", 3840, 2160), ("arch", 1920, 1080), ("bunny", 7680, 4320)]
+FULL = [("bunny", 3840, 2160), ("bunny", 1920, 1080), ("shadows", 3840, 2160), ("arch", 1920, 1080), ("cube", 640, 480), ("bunny", 7680, 4320)]
 
 
 @pytest.mark.parametrize("name,W,H", FULL)
@@ -386,14 +386,16 @@ def test_frames_in_flight_share_one_scene():
         slots[k].close()
 
 
-@pytest.mark.parametrize("shot", ["arch1", "arch2", "cube1", "cube2", "cube3"])
+@pytest.mark.parametrize("shot", ["arch1", "arch2", "cube1", "cube2", "cube3", "shadows1", "shadows2", "shadows4", "shadows5"])
 def test_hip_frame_against_the_reference_screenshots(renderer, shot):
     """The HIP path at the camera states of the reference's own screenshots (tests/conftest.py::REFERENCE_SHOTS),
     2560x1377: identical to the oracle on every pixel, and compared DIRECTLY with the reference's window grab
     (tests/golden/ref_*_stride4.png): <= 1 LSB for the arch grabs (all but 4 pixels of arch2 at full size),
-    texel/silhouette pixels only for the crate."""
+    texel/silhouette pixels only for the crate; for the four Scenes/shadows.txt grabs (the MESH path: octree walk for
+    primary and shadow rays) also the full-resolution crop around the pear — all but a few dozen shadow-edge pixels
+    within 1 LSB, 99.8 % identical."""
     from PIL import Image
-    from conftest import CLIENT_H, CLIENT_W, load_reference_shot
+    from conftest import CLIENT_H, CLIENT_W, SHADOWS_CROP, load_reference_shot
     scene = load_reference_shot(shot)
     _setup(renderer, scene, CLIENT_W, CLIENT_H)
     renderer.render()
@@ -405,6 +407,12 @@ def test_hip_frame_against_the_reference_screenshots(renderer, shot):
     d = np.abs(img[::4, ::4] - ref).max(axis=2)
     if shot.startswith("arch"):
         assert (d > 1).sum() <= 4 and (d > 0).mean() < 0.02
+    elif shot.startswith("shadows"):
+        assert (d > 1).sum() <= 8 and (d > 0).mean() < 1e-3
+        y0, y1, x0, x1 = SHADOWS_CROP
+        crop = np.asarray(Image.open(os.path.join(GOLDEN, f"ref_{shot}_crop_y{y0}_x{x0}.png")).convert("RGB")).astype(np.int16)
+        dc = np.abs(img[y0:y1, x0:x1] - crop).max(axis=2)
+        assert (dc > 1).sum() <= 64 and (dc == 0).mean() > 0.998, ((dc > 1).sum(), (dc == 0).mean())
     else:
         assert (d > 2).mean() < 5e-4
 
