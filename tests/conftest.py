@@ -50,6 +50,11 @@ REFERENCE_SHOTS = {
     "arch2": dict(scene="arch", v=(0.0, 0.0, math.tanh(9209.8 / 5000.0)), t=5.761, interval=-1),
     # Scenes/shadows.txt (README.md:117-122): camera at rest, only the clock is unknown.  The pear is a mesh: these four
     # pin the OBJ loader, the octree builder and the octree walk (primary and shadow rays) on the reference's output.
+    # Scenes/soccer.txt "Stationary sphere" (README.md:124-125): the grab was taken with the ball at rest and turned by
+    # 2 rad about y (the `p` line's angle/axis; found by tests/golden/fit_reference_camera.py::fit_sphere_rotation) —
+    # with exactly that, EVERY pixel of the grab is within 1 LSB.  Pins the textured-sphere (u,v) of
+    # opencl_kernel.cl:356-357 (atan2 / asin) and the bilinear fetch on a sphere.
+    "sphere_stationary": dict(text="TTextures/soccer.jpg\nOs\n p0,0,5,2,0,1,0,2,2,2\n t0\n v0,0,0\nR\n", v=(0.0, 0.0, 0.0), t=0.0, interval=-1),
     "shadows1": dict(scene="shadows", v=(0.0, 0.0, 0.0), t=6.157, interval=-1),
     "shadows2": dict(scene="shadows", v=(0.0, 0.0, 0.0), t=9.212, interval=-1),
     "shadows4": dict(scene="shadows", v=(0.0, 0.0, 0.0), t=18.229, interval=-1),
@@ -68,7 +73,11 @@ CLIENT_W, CLIENT_H = 2560, 1377      # client area of the reference's 2560x1400 
 def load_reference_shot(name):
     from relativitypathtracer_amd import Scene
     c = REFERENCE_SHOTS[name]
-    s = Scene.from_file(c["scene"])
+    if "text" in c:
+        s = Scene()
+        s.inputScene(c["text"])
+    else:
+        s = Scene.from_file(c["scene"])
     s.set_camera(c["v"], c["t"])
     s.set_interval(c["interval"])
     s.update_objects()

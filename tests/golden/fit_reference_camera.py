@@ -26,6 +26,11 @@ Results (kept in tests/conftest.py::REFERENCE_SHOTS; tests/test_oracle.py checks
              24 / 31 / 33 / 55 of 3 525 120 pixels off by > 1 LSB (105 / 93 / 218 / 1 761 differ at all);
              one millisecond earlier or later 47..79 / 248..297 / 95..97 / 92..124, three away 264 / 840 / 298 / 322.
              Of the pear's own 34 099 pixels, 0 / 0 / 1 / 0 are off by > 1 LSB and 0 / 1 / 25 / 47 differ at all.
+  sphere_stationary.png (Scenes/soccer.txt with the ball at rest): the ball of the grab is turned against the scene
+             file's; a search over 13 axes x 126 angles at quarter resolution, then over the angle in steps of 0.004 rad
+             at full size, ends at EXACTLY `p0,0,5,2,0,1,0,2,2,2` (2 rad about y): 0 of 3 525 120 pixels off by more than
+             1 LSB; 40 000 at 2 +- 0.004 rad.  sphere_moving.png is not reproduced by any (angle about y, clock) pair
+             with the scene file's v = 0.9c and stays unpinned.
 The residual pixels of the cube grabs are crate-texture texels (the reference decodes box.jpg with CImg/libjpeg,
 the harness with Pillow) and silhouette pixels, as for the static cube1.png.
 """
@@ -78,7 +83,32 @@ def search(scene_name, shot, axis, interval, k_range, ms_range, rows):
     return best
 
 
+def fit_sphere_rotation():
+    """Scenes/soccer.txt, ball at rest: which rotation of the `p` line reproduces sphere_stationary.png?"""
+    import itertools
+    ref = grab("sphere_stationary")
+    small = np.asarray(Image.fromarray(ref.astype(np.uint8)).resize((640, 344), Image.BOX)).astype(np.int16)
+
+    def frame(angle, axis, w, h):
+        s = Scene()
+        s.inputScene("TTextures/soccer.jpg\nOs\n p0,0,5,%.6f,%d,%d,%d,2,2,2\n t0\n v0,0,0\nR\n" % (angle, *axis))
+        s.set_camera((0, 0, 0), 0.0)
+        s.update_objects()
+        px, _, _ = oracle_ffi.render(s, w, h, want_rgb=False)
+        return px["rgba"].reshape(h, w, 4)[::-1, :, :3].astype(np.int16)
+    axes = []
+    for a in itertools.product((-1, 0, 1), repeat=3):
+        if a != (0, 0, 0) and tuple(-x for x in a) not in axes:
+            axes.append(a)
+    coarse = min((float(np.abs(frame(i * 0.05, a, 640, 344) - small).mean()), a, i * 0.05) for a in axes for i in range(126))
+    print("sphere_stationary coarse", coarse)          # (1.0, (0, -1, 0), 4.3) == 1.98 rad about +y
+    for i in range(-5, 6):
+        ang = 2.0 + 0.004 * i
+        print("sphere_stationary angle", ang, int((np.abs(frame(ang, (0, 1, 0), W, H) - ref).max(axis=2) > 1).sum()))
+
+
 if __name__ == "__main__":
+    fit_sphere_rotation()
     # windows around the optima; the coarse stages (bounding box of the crate vs. clock, 8x box-filtered SSD of the
     # arch vs. clock at v = 0.95, then the valley rapidity + clock = const) are how the windows were found
     search("cube", "cube2", 0, 0, range(73600, 73860, 10), [0], (826, 1377))

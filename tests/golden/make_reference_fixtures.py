@@ -30,6 +30,11 @@ bar; the client area is 2560x1377.
                          finds 6.157 s, 9.212 s, 18.229 s and 25.987 s.  The crop holds the pear, the part of its shadow
                          next to it and (shadows4/5) the light.
 
+  sphere_stationary.png  Scenes/soccer.txt "Stationary sphere" (README.md:124-125): a textured sphere at rest, turned by
+                         2 rad about y when the grab was taken (recovered by fit_reference_camera.py): sphere (u,v) through
+                         atan2/asin and the bilinear fetch.  sphere_moving.png could not be reproduced from any
+                         (rotation about y, clock) pair and stays out.
+
 Written per image: an exact stride-4 subsample of the client area (every 4th pixel of every 4th row, no
 filtering) and one full-resolution crop of the part with the most detail.
 """
@@ -48,6 +53,7 @@ CROPS = {
     "cube2": (826, 1377, 1150, 1410),    # the length-contracted crate
     "cube3": (826, 1377, 1000, 1620),    # the crate as seen with light delay (Terrell rotation)
     "arch2": (900, 1300, 960, 1600),     # brick floor under the arch: the most position-sensitive texture
+    "sphere_stationary": (380, 1020, 960, 1600),   # the whole ball
     "shadows1": (540, 980, 1200, 1720),  # the pear (mesh path), dimly lit from the left
     "shadows2": (540, 980, 1200, 1720),
     "shadows4": (540, 980, 1200, 1720),  # the pear lit from the right, its shadow on the wall, the light sphere

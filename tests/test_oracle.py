@@ -101,6 +101,24 @@ def test_reference_screenshot_cube_moving_camera(shot, crop, fixture):
         assert (np.abs(off - ref_crop).max(axis=2) > 1).sum() > 20000
 
 
+def test_reference_screenshot_sphere_stationary_textured_sphere():
+    """Screenshots/sphere_stationary.png (README.md:124-125): a textured sphere at rest — sphere (u,v) through atan2 and
+    asin (opencl_kernel.cl:356-357) and the bilinear fetch.  The grab was taken with the ball turned by 2 rad about y
+    (REFERENCE_SHOTS); with that, every pixel of the grab is within 1 LSB, and 0.004 rad away 40 000 are not."""
+    img = _render_top_down("sphere_stationary")
+    d = np.abs(img[::4, ::4] - _load("ref_sphere_stationary_stride4.png"))
+    assert d.max() <= 1, f"stride-4 subsample: max byte difference {d.max()}"
+    ref_crop = _load("ref_sphere_stationary_crop_y380_x960.png")
+    crop = np.abs(img[380:1020, 960:1600] - ref_crop)
+    assert crop.max() <= 1, f"full-resolution crop of the ball: max byte difference {crop.max()}"
+    # (a third of the ball's channel values differ by exactly one level: soccer.jpg decoded by CImg/libjpeg there, Pillow here)
+    s = Scene()
+    s.inputScene(REFERENCE_SHOTS["sphere_stationary"]["text"].replace("p0,0,5,2,", "p0,0,5,2.004,"))
+    s.update_objects()
+    off = _render_top_down("sphere_stationary", rows=(380, 1020), scene=s)[:, 960:1600]
+    assert (np.abs(off - ref_crop).max(axis=2) > 1).sum() > 20000
+
+
 def shadows_pear_mask():
     """Client-area pixels (top-down) whose primary ray hits the pear: the mesh object alone, light propagation off."""
     s = load_reference_shot("shadows1")
