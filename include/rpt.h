@@ -105,8 +105,17 @@ int rpt_set_debug_rgb(rpt_ctx *ctx, void *device_ptr_or_null_or_1);
  *   15, 16    + walk with neighbour prefetch and branch-free triangle pairs (uncapped / 4 waves)
  *   25, 26, 27  per-tile object masks from the prepass, 4 / 5 / 6 waves per SIMD
  *   28  masks + triangle-record prefetch;  31  masks + the pipelined walk
+ *   40, 41, 42  no prepass: every wavefront builds its own object mask from per-object image-plane rectangles
+ *               (computed on the host in rpt_set_objects) with one lane-parallel test + __ballot; 4 / 5 / 6 waves per SIMD
  *   7, 8, 11  diagnostic builds (loop counters, primary rays only, per-wave timeline): not product paths */
 int rpt_set_variant(rpt_ctx *ctx, int variant);
+
+/* The per-object cull record of the default kernel, exposed for tests (host code, needs no device): the rectangle
+ * {u0, v0, u1, v1} on the camera's image plane z = 0.5 (pixel (x, y) of a W x H frame looks through
+ * ((x/W - 0.5) * W/H, y/H - 0.5)) outside which no primary ray can reach `object` (one 320-B Object with its per-frame
+ * Lorentz / stationaryCam fields set).  root_bounds: min.xyz, max.xyz of a mesh object's octree root, else NULL.
+ * +-3e38 on every side = never culled; u0 > u1 = not visible at all. */
+int rpt_object_screen_rect(const void *object, int interval, const float *root_bounds_or_null, float rect_out[4]);
 
 /* Render one frame and wait for it (the reference's runKernel + finish). */
 int rpt_render(rpt_ctx *ctx);

@@ -17,6 +17,7 @@
 #include "../../include/rpt.h"
 #include "rpt_kernels.hip.h"
 #include "rpt_octree_build.hip.h"
+#include "rpt_screen_bounds.hpp"
 
 #pragma clang fp contract(off)
 
@@ -287,6 +288,17 @@ void build_dobjs(const rpt_ctx *ctx, const rpt_object *objs, int count, rptd::DO
     }
 }
 
+// Per-frame image-plane rectangle of every object (rpt_screen_bounds.hpp) for the in-kernel lane-parallel cull.
+void build_rects(const rpt_ctx *ctx, const rpt_object *objs, int count, rptb::Rect *out) {
+    for (int i = 0; i < count; i++) {
+        const rpt_object &o = objs[i];
+        const float *root = nullptr;
+        if (o.type == RPT_MESH && o.meshIndex >= 0 && (size_t)o.meshIndex * 6 + 5 < ctx->geo->host_node_bounds.size())
+            root = &ctx->geo->host_node_bounds[(size_t)o.meshIndex * 6];
+        out[i] = rptb::object_rect(o, ctx->interval, root);
+    }
+}
+
 int validate_objects(rpt_ctx *ctx, const rpt_object *objs, int count) {
     for (int i = 0; i < count; i++) {
         const rpt_object &o = objs[i];
@@ -343,6 +355,7 @@ int launch(rpt_ctx *ctx) {
     a.dtris = (const rptd::DTri *)ctx->geo->dtris.ptr;
     a.dobjs = (const rptd::DObj *)((const char *)ctx->objects.ptr + (size_t)ctx->object_count * sizeof(rpt_object));
     a.objects = (const rpt_object *)ctx->objects.ptr;
+    a.rects = (const float4 *)((const char *)ctx->objects.ptr + (size_t)ctx->object_count * (sizeof(rpt_object) + sizeof(rptd::DObj)));
     a.vertices = (const rpt_float3 *)ctx->geo->vertices.ptr;
     a.normals = (const rpt_float3 *)ctx->geo->normals.ptr;
     a.uvs = (const rpt_float2 *)ctx->geo->uvs.ptr;
@@ -421,6 +434,9 @@ int launch(rpt_ctx *ctx) {
         break;
     }
     case 8: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only, grid, dim3(256), 0, ctx->stream, a); break;
+    case 40: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w4, grid, dim3(256), 0, ctx->stream, a); break;
+    case 41: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w5, grid, dim3(256), 0, ctx->stream, a); break;
+    case 42: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w6, grid, dim3(256), 0, ctx->stream, a); break;
     default: return fail(ctx, RPT_ERR_ARG, "unknown kernel variant");
     }
     RPT_HIP(ctx, hipGetLastError());
@@ -533,7 +549,7 @@ int rpt_set_objects(rpt_ctx *ctx, const void *objects, int count) {
     RPT_HIP(ctx, hipSetDevice(ctx->device));
     if (int rc = validate_objects(ctx, (const rpt_object *)objects, count)) return rc;
     const size_t bytes = (size_t)count * sizeof(rpt_object);
-    const size_t dbytes = (size_t)count * sizeof(rptd::DObj);
+    const size_t dbytes = (size_t)count * (sizeof(rptd::DObj) + sizeof(rptb::Rect));     // DObj[count] then Rect[count]
     // staging ring of pinned slots: the copy of frame k may still be in flight when frame k+1 is staged, so
     // each slot has an event and is reused only once its own transfer has completed (no per-frame stream sync)
     const size_t slot_bytes = ((bytes + dbytes + 255) / 256) * 256;
@@ -558,6 +574,7 @@ int rpt_set_objects(rpt_ctx *ctx, const void *objects, int count) {
         char *slot = (char *)ctx->pinned_objects + (ctx->pinned_capacity / RPT_STAGING_SLOTS) * k;
         std::memcpy(slot, objects, bytes);
         build_dobjs(ctx, (const rpt_object *)objects, count, (rptd::DObj *)(slot + bytes));
+        build_rects(ctx, (const rpt_object *)objects, count, (rptb::Rect *)(slot + bytes + (size_t)count * sizeof(rptd::DObj)));
         RPT_HIP(ctx, hipMemcpyAsync(ctx->objects.ptr, slot, bytes + dbytes, hipMemcpyHostToDevice, ctx->stream));
         RPT_HIP(ctx, hipEventRecord(ctx->staging_done[k], ctx->stream));
         ctx->staging_used |= 1u << k;
@@ -621,8 +638,15 @@ int rpt_set_debug_rgb(rpt_ctx *ctx, void *p) {
     return RPT_OK;
 }
 
+int rpt_object_screen_rect(const void *object, int interval, const float *root_bounds_or_null, float rect_out[4]) {
+    if (!object || !rect_out) return RPT_ERR_ARG;
+    const rptb::Rect r = rptb::object_rect(*(const rpt_object *)object, interval, root_bounds_or_null);
+    rect_out[0] = r.u0; rect_out[1] = r.v0; rect_out[2] = r.u1; rect_out[3] = r.v1;
+    return RPT_OK;
+}
+
 int rpt_set_variant(rpt_ctx *ctx, int variant) {
-    if (!ctx || variant < 0 || variant > 31) return RPT_ERR_ARG;
+    if (!ctx || variant < 0 || variant > 63) return RPT_ERR_ARG;
     ctx->variant = variant;
     return RPT_OK;
 }

@@ -87,6 +87,8 @@ struct KernelArgs {
     // per-tile object masks: 8x8-pixel tiles of this context's rows, classified once per frame by rpt_tile_bin_kernel
     int tiles_x, n_tiles;                    // tiles per row, tiles in this context's rows
     unsigned long long *tile_masks;          // [n_tiles] bit i = primary rays of the tile may hit object i (i < 64)
+    // per-object image-plane rectangles (rpt_screen_bounds.hpp), tested lane-parallel by each wavefront (V >= 20)
+    const float4 *rects;                     // [object_count] u0, v0, u1, v1 on the plane z = 0.5
 };
 
 struct Hit {                 // opencl_kernel.cl:38-44
@@ -850,6 +852,24 @@ RPT_DEV uint32_t tonemap_pack(const KernelArgs &a, f3 color, f3 &mapped) {
     return to_u8(mapped.x) | (to_u8(mapped.y) << 8) | (to_u8(mapped.z) << 16) | (1u << 24);
 }
 
+// The wavefront's object mask, computed by the wavefront itself: lane i compares the image-plane rectangle of object i
+// (rpt_screen_bounds.hpp: outside it no primary ray reaches the object) with the wave's 8x8-pixel tile, grown by a pixel
+// and a half on every side, and one __ballot makes the 64 answers the mask — in SGPRs, wave-uniform, with no prepass
+// kernel, no mask buffer and no dependent load behind it.  Pixel (x, y) looks through the plane point
+// ((x/W - 0.5) * aspect, y/H - 0.5) (opencl_kernel.cl:57-63).  NaNs compare false, so a broken rectangle keeps its object.
+RPT_DEV unsigned long long wave_object_mask(const KernelArgs &a, int tile_x0, int tile_y0) {
+    const int lane = threadIdx.x & 63;
+    bool keep = false;
+    if (lane < a.object_count) {
+        const float4 r = a.rects[lane];
+        const float iw = 1.0f / (float)a.width, ih = 1.0f / (float)a.height;
+        const float tu0 = (((float)tile_x0 - 1.5f) * iw - 0.5f) * a.aspect, tu1 = (((float)tile_x0 + 8.5f) * iw - 0.5f) * a.aspect;
+        const float tv0 = ((float)tile_y0 - 1.5f) * ih - 0.5f, tv1 = ((float)tile_y0 + 8.5f) * ih - 0.5f;
+        keep = !(r.z < tu0 || r.x > tu1 || r.w < tv0 || r.y > tv1);
+    }
+    return __ballot(keep);
+}
+
 // ---------------------------------------------------------------------------------------------
 // One thread per pixel, wave = 8x8 tile, workgroup = 32x8 strip.
 //   V = 0: reads the reference layouts only (general fallback, any valid octree)
@@ -882,7 +902,9 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
         const int tile = __builtin_amdgcn_readfirstlane(tile_row * a.tiles_x + (int)blockIdx.x * 4 + wave);
         object_mask = a.tile_masks[tile];
     }
-    if ((V != 10 && V != 11 && V != 12) || object_mask != 0 || a.object_count > 64) {
+    if (V >= 20) object_mask = wave_object_mask(a, (int)blockIdx.x * 32 + wave * 8, global_tile * RPT_TILE_ROWS);
+    const bool masked = V == 10 || V == 11 || V == 12 || V >= 20;
+    if (!masked || object_mask != 0 || a.object_count > 64) {
         const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);
         if (trace<V>(a, camdir, object_mask, color)) packed = tonemap_pack(a, color, mapped);
     }
@@ -929,6 +951,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_v1_masked_w6(const KernelArgs a) { render_pixel_body<10>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_masked_pipe_w4(const KernelArgs a) { render_pixel_body<12>(a); }
 __global__ __launch_bounds__(256) void rpt_render_kernel_primary_only(const KernelArgs a) { render_pixel_body<3>(a); }
+// V = 20: the wave's object mask from the per-object screen rectangles by lane-parallel test + __ballot (no prepass)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_ballot_w4(const KernelArgs a) { render_pixel_body<20>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_w5(const KernelArgs a) { render_pixel_body<20>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_ballot_w6(const KernelArgs a) { render_pixel_body<20>(a); }
 
 // ---------------------------------------------------------------------------------------------
 // Tile-mask prepass (one thread per 8x8 tile).  For every object it asks whether ANY primary ray

@@ -1,0 +1,415 @@
+// rpt_screen_bounds.hpp — per object, per frame: a conservative rectangle on the camera's image plane outside
+// which no primary ray can reach the object.  Host code (double precision), run in rpt_set_objects; the render
+// kernel turns the rectangles into a per-wavefront object mask with ONE lane-parallel overlap test and a __ballot
+// (rpt_kernels.hip.h), so no pixel-space prepass and no second launch is needed.
+//
+// What is bounded is the reference's own ray set-up (opencl_kernel.cl:382-390): a primary ray with camera direction
+// nd is, for object i, the object-space ray   origin oc = InvM * stationaryCam.yzw,
+//                                             dir    F(nd) = InvM3 * (Lorentz * (interval, nd))[1..3].
+// The object lies inside a bounding shape B in object space (the unit sphere, the cube [-1,1]^3, a mesh's root box), so a
+// ray can only hit it if F(nd) lies in K = { directions from oc that meet B }, a convex cone.  F is a homeomorphism of the
+// direction sphere (aberration = a Moebius map, then a linear map), so the region of camera directions to be kept is
+// bounded by G(boundary of K), G = F^-1:  the silhouette curve of B is sampled, every sample is mapped to a camera
+// direction and CHECKED by pushing it through F again with the very matrices the kernel uses, and the rectangle is the
+// bounding box of the samples' image-plane positions (plane z = 0.5: u = x/2z, v = y/2z), grown by a margin that covers
+// the curve between samples.  Parts of the curve behind the camera are clipped at the cone nd.z = EPS |nd| (far outside
+// any screen); every doubtful case — origin inside or near B, non-finite numbers, a failed check, a clipped region that
+// spreads over more than a third of the horizon — returns the full plane.  Arithmetic here may be approximate: it only
+// decides which exact tests are skipped, and a skipped test is one the reference would have failed for every pixel.
+#pragma once
+#include <algorithm>
+#include <cmath>
+
+#include "../../include/rpt_layout.h"
+
+namespace rptb {
+
+struct Rect { float u0, v0, u1, v1; };      // keep the object for a tile iff the tile's plane rectangle overlaps this one
+
+inline Rect full_rect() { return Rect{-3.0e38f, -3.0e38f, 3.0e38f, 3.0e38f}; }
+inline Rect empty_rect() { return Rect{3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f}; }
+
+namespace detail {
+
+constexpr double EPS_FRONT = 0.02;          // directions with nd.z <= EPS |nd| are treated as behind the camera
+
+struct D3 { double x, y, z; };
+inline D3 sub(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline D3 add(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline D3 mul(D3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline D3 cross(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double len(D3 a) { return std::sqrt(dot(a, a)); }
+inline bool finite3(D3 a) { return std::isfinite(a.x) && std::isfinite(a.y) && std::isfinite(a.z); }
+
+inline bool invert3(const double m[3][3], double out[3][3]) {
+    const double c00 = m[1][1] * m[2][2] - m[1][2] * m[2][1], c01 = m[1][2] * m[2][0] - m[1][0] * m[2][2], c02 = m[1][0] * m[2][1] - m[1][1] * m[2][0];
+    const double det = m[0][0] * c00 + m[0][1] * c01 + m[0][2] * c02;
+    if (!std::isfinite(det) || std::fabs(det) < 1.0e-300) return false;
+    const double id = 1.0 / det;
+    out[0][0] = c00 * id; out[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * id; out[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * id;
+    out[1][0] = c01 * id; out[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) * id; out[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) * id;
+    out[2][0] = c02 * id; out[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) * id; out[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) * id;
+    return true;
+}
+
+// The two maps of one object.
+struct DirMap {
+    double L[4][4], Linv[4][4], LsInv[3][3], M3[3][3], InvM3[3][3];
+    int interval = -1;
+    bool ok = false;
+    bool linear = false;      // G(u) (before normalisation) is linear in u: straight object-space edges stay straight on the image plane
+
+    // camera direction (any length) -> object-space direction, with the kernel's matrices (opencl_kernel.cl:386-388, 214)
+    D3 F(D3 nd) const {
+        const double l = len(nd);
+        const double v[4] = {(double)interval, nd.x / l, nd.y / l, nd.z / l};
+        double r[3];
+        for (int i = 0; i < 3; i++) r[i] = L[i + 1][0] * v[0] + L[i + 1][1] * v[1] + L[i + 1][2] * v[2] + L[i + 1][3] * v[3];
+        return {InvM3[0][0] * r[0] + InvM3[0][1] * r[1] + InvM3[0][2] * r[2], InvM3[1][0] * r[0] + InvM3[1][1] * r[1] + InvM3[1][2] * r[2],
+                InvM3[2][0] * r[0] + InvM3[2][1] * r[1] + InvM3[2][2] * r[2]};
+    }
+    // object-space direction -> camera direction (not normalised); false when no such direction exists
+    bool G(D3 u, D3 &nd) const {
+        const double r[3] = {M3[0][0] * u.x + M3[0][1] * u.y + M3[0][2] * u.z, M3[1][0] * u.x + M3[1][1] * u.y + M3[1][2] * u.z,
+                             M3[2][0] * u.x + M3[2][1] * u.y + M3[2][2] * u.z};
+        if (interval == 0) {
+            nd = {LsInv[0][0] * r[0] + LsInv[0][1] * r[1] + LsInv[0][2] * r[2], LsInv[1][0] * r[0] + LsInv[1][1] * r[1] + LsInv[1][2] * r[2],
+                  LsInv[2][0] * r[0] + LsInv[2][1] * r[1] + LsInv[2][2] * r[2]};
+            return finite3(nd) && len(nd) > 0.0;
+        }
+        // interval = -1: (interval, nd) is a past-directed null vector and stays one under Lorentz
+        const double rl = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        const double k[4] = {-rl, r[0], r[1], r[2]};
+        double c[4];
+        for (int i = 0; i < 4; i++) c[i] = Linv[i][0] * k[0] + Linv[i][1] * k[1] + Linv[i][2] * k[2] + Linv[i][3] * k[3];
+        nd = {c[1], c[2], c[3]};
+        return c[0] < 0.0 && finite3(nd) && len(nd) > 0.0;
+    }
+    // rest-frame direction (Lorentz * (interval, nd))[1..3] -> camera direction, interval = -1 only
+    bool G_rest(D3 r, D3 &nd) const {
+        const double rl = len(r);
+        const double k[4] = {-rl, r.x, r.y, r.z};
+        double c[4];
+        for (int i = 0; i < 4; i++) c[i] = Linv[i][0] * k[0] + Linv[i][1] * k[1] + Linv[i][2] * k[2] + Linv[i][3] * k[3];
+        nd = {c[1], c[2], c[3]};
+        return c[0] < 0.0 && finite3(nd) && len(nd) > 0.0;
+    }
+    D3 to_rest(D3 u) const {
+        return {M3[0][0] * u.x + M3[0][1] * u.y + M3[0][2] * u.z, M3[1][0] * u.x + M3[1][1] * u.y + M3[1][2] * u.z,
+                M3[2][0] * u.x + M3[2][1] * u.y + M3[2][2] * u.z};
+    }
+    // Aberration case (interval = -1, G not linear).  The object-space directions `dirs` span the cone K of rays that can
+    // meet the bounding shape.  In the object's rest frame K lies inside the circular cone around `axis_obj` of half-angle
+    // beta' = the largest angle to any of `dirs` (they are K's extreme rays, or samples of them; a margin is added).  The
+    // camera sees rest-frame directions through a Lorentz transformation of null vectors, i.e. a Moebius map of the
+    // direction sphere, and those map circles to circles: the circular cone becomes a spherical cap {n.c >= cos(beta)} that
+    // contains every camera direction to be kept.  True when that cap is small (< 80 deg) and lies wholly in front of the
+    // camera's clip cone — then the kept region is a bounded patch of the image plane and the bounding box of its sampled
+    // outline (plus margin) contains it.  False = no statement, use the full plane.
+    bool cap_in_front(const D3 *dirs, int n, D3 axis_obj) const {
+        D3 a = to_rest(axis_obj);
+        const double la = len(a);
+        if (!(la > 0.0)) return false;
+        a = mul(a, 1.0 / la);
+        double cmin = 1.0;
+        for (int i = 0; i < n; i++) {
+            const D3 r = to_rest(dirs[i]);
+            const double lr = len(r);
+            if (!(lr > 0.0)) return false;
+            cmin = std::min(cmin, dot(a, r) / lr);
+        }
+        const double beta_rest = std::acos(std::max(-1.0, std::min(1.0, cmin))) * 1.03 + 0.01;
+        if (!(beta_rest < 1.45)) return false;
+        const D3 helper = std::fabs(a.x) < 0.6 ? D3{1, 0, 0} : D3{0, 1, 0};
+        D3 e1 = cross(a, helper);
+        e1 = mul(e1, 1.0 / len(e1));
+        const D3 e2 = cross(a, e1);
+        D3 p[6], pc;
+        const double cbr = std::cos(beta_rest), sbr = std::sin(beta_rest);
+        static const double C6[6] = {1.0, 0.5, -0.5, -1.0, -0.5, 0.5}, S6[6] = {0.0, 0.8660254037844386, 0.8660254037844386, 0.0, -0.8660254037844386, -0.8660254037844386};
+        for (int i = 0; i < 6; i++) {
+            const D3 r = add(mul(a, cbr), mul(add(mul(e1, C6[i]), mul(e2, S6[i])), sbr));
+            if (!G_rest(r, p[i])) return false;
+            p[i] = mul(p[i], 1.0 / len(p[i]));
+        }
+        if (!G_rest(a, pc)) return false;
+        pc = mul(pc, 1.0 / len(pc));
+        D3 c = cross(sub(p[2], p[0]), sub(p[4], p[0]));
+        const double lc = len(c);
+        if (!(lc > 1.0e-12)) return false;
+        c = mul(c, 1.0 / lc);
+        if (dot(c, pc) < dot(c, p[0])) c = mul(c, -1.0);
+        const double cb = dot(c, p[0]);
+        for (int i = 0; i < 6; i++) if (std::fabs(dot(c, p[i]) - cb) > 1.0e-6) return false;      // not a circle: something is off
+        if (!(dot(c, pc) > cb)) return false;
+        const double beta = std::acos(std::max(-1.0, std::min(1.0, cb)));
+        const double tilt = std::acos(std::max(-1.0, std::min(1.0, c.z)));
+        return beta < 1.40 && tilt + beta < std::acos(EPS_FRONT) - 0.05;
+    }
+    // G, verified through F: the angle between F(G(u)) and u must vanish
+    bool G_checked(D3 u, D3 &nd) const {
+        if (!G(u, nd)) return false;
+        const D3 back = F(nd);
+        const double lb = len(back), lu = len(u);
+        if (!(lb > 0.0) || !(lu > 0.0) || !std::isfinite(lb)) return false;
+        return dot(back, u) > 0.0 && len(cross(back, u)) <= 1.0e-4 * lb * lu;
+    }
+};
+
+inline DirMap make_map(const rpt_object &o, int interval) {
+    DirMap m;
+    m.interval = interval;
+    if (interval != 0 && interval != -1) return m;
+    const rpt_float4 *Lr = o.Lorentz, *Mr = o.M, *Ir = o.InvM;
+    for (int r = 0; r < 4; r++) { m.L[r][0] = Lr[r].x; m.L[r][1] = Lr[r].y; m.L[r][2] = Lr[r].z; m.L[r][3] = Lr[r].w; }
+    for (int r = 0; r < 3; r++) {
+        m.M3[r][0] = Mr[r].x; m.M3[r][1] = Mr[r].y; m.M3[r][2] = Mr[r].z;
+        m.InvM3[r][0] = Ir[r].x; m.InvM3[r][1] = Ir[r].y; m.InvM3[r][2] = Ir[r].z;
+    }
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) if (!std::isfinite(m.L[r][c])) return m;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) if (!std::isfinite(m.M3[r][c]) || !std::isfinite(m.InvM3[r][c])) return m;
+    if (interval == 0) {
+        double ls[3][3];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) ls[r][c] = m.L[r + 1][c + 1];
+        if (!invert3(ls, m.LsInv)) return m;
+        m.linear = true;
+    } else {
+        // the caller's InvLorentz serves as the inverse (the kernel shades with it): every use below is checked through F
+        const rpt_float4 *Jr = o.InvLorentz;
+        for (int r = 0; r < 4; r++) { m.Linv[r][0] = Jr[r].x; m.Linv[r][1] = Jr[r].y; m.Linv[r][2] = Jr[r].z; m.Linv[r][3] = Jr[r].w; }
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) if (!std::isfinite(m.Linv[r][c])) return m;
+        m.linear = m.Linv[1][0] == 0.0 && m.Linv[2][0] == 0.0 && m.Linv[3][0] == 0.0;
+    }
+    m.ok = true;
+    return m;
+}
+
+// Accumulates the image-plane bounding box of a sampled closed or open curve of object-space directions.
+struct Accum {
+    const DirMap &m;
+    double u0 = 1e300, v0 = 1e300, u1 = -1e300, v1 = -1e300;
+    bool failed = false, any_front = false, any_near_behind = false;
+    double crossing_angles[32];
+    int n_crossings = 0;
+    explicit Accum(const DirMap &map) : m(map) {}
+
+    static double frontness(D3 nd) { return nd.z - EPS_FRONT * len(nd); }
+    void take(D3 nd) {      // a direction in front of the camera
+        const double u = 0.5 * nd.x / nd.z, v = 0.5 * nd.y / nd.z;
+        u0 = std::min(u0, u); u1 = std::max(u1, u); v0 = std::min(v0, v); v1 = std::max(v1, v);
+    }
+    // one sample; returns its camera direction in nd (valid unless failed).  `verify`: push it through F again
+    // (done at the end points of every edge and at every fourth sample of a circle; a wrong inverse shows there too)
+    bool sample(D3 u_obj, D3 &nd, bool &front, bool verify = true) {
+        if (!(verify ? m.G_checked(u_obj, nd) : m.G(u_obj, nd))) { failed = true; return false; }
+        front = frontness(nd) > 0.0;
+        if (front) { take(nd); any_front = true; }
+        else if (nd.z > -0.2 * len(nd)) any_near_behind = true;
+        return true;
+    }
+    void take_mapped(D3 nd, bool &front) {     // a sample whose camera direction is already known
+        front = frontness(nd) > 0.0;
+        if (front) { take(nd); any_front = true; }
+        else if (nd.z > -0.2 * len(nd)) any_near_behind = true;
+    }
+    // the curve between two consecutive samples crosses the clip cone: locate the crossing by bisection on the
+    // object-space segment between them (exact for straight edges, close enough for arcs: the margin covers it)
+    void crossing(D3 ua, D3 ub, bool front_a) {
+        D3 lo = ua, hi = ub;      // lo on the front side when front_a, else hi
+        for (int it = 0; it < 18; it++) {
+            const D3 mid = mul(add(lo, hi), 0.5);
+            D3 nd;
+            if (!m.G(mid, nd)) { failed = true; return; }
+            const bool f = frontness(nd) > 0.0;
+            if (f == front_a) lo = mid; else hi = mid;
+        }
+        D3 nd;
+        if (!m.G_checked(front_a ? lo : hi, nd) || !(nd.z > 0.0)) { failed = true; return; }
+        take(nd);
+        any_front = true;
+        if (n_crossings >= 32) { failed = true; return; }
+        crossing_angles[n_crossings++] = std::atan2(nd.y, nd.x);
+    }
+    // after all samples: does the clipped part spread over too much of the horizon to be bounded by its end points?
+    bool horizon_span_too_wide() const {
+        if (n_crossings < 2) return false;
+        double a[32];
+        std::copy(crossing_angles, crossing_angles + n_crossings, a);
+        std::sort(a, a + n_crossings);
+        double gap = a[0] + 2.0 * M_PI - a[n_crossings - 1];
+        for (int i = 1; i < n_crossings; i++) gap = std::max(gap, a[i] - a[i - 1]);
+        return 2.0 * M_PI - gap > 2.0 * M_PI / 3.0;
+    }
+};
+
+inline Rect finish(const Accum &acc, double rel_margin, const DirMap &m, D3 centre_dir) {
+    if (acc.failed) return full_rect();
+    if (!acc.any_front) return acc.any_near_behind ? full_rect() : empty_rect();      // wholly (and well) behind the camera
+    if (acc.horizon_span_too_wide()) return full_rect();
+    // the inside of the sampled curve must be the bounded side: the direction to the shape's centre, when it is in front
+    // of the camera, has to land inside the box
+    D3 ndc;
+    if (!m.G_checked(centre_dir, ndc)) return full_rect();
+    if (Accum::frontness(ndc) > 0.0) {
+        const double u = 0.5 * ndc.x / ndc.z, v = 0.5 * ndc.y / ndc.z;
+        if (!(u >= acc.u0 && u <= acc.u1 && v >= acc.v0 && v <= acc.v1)) return full_rect();
+    } else if (!m.linear) {
+        return full_rect();
+    }
+    // margins relative to the part of the box that can matter (screens reach |u| <= aspect/2, |v| <= 1/2; clipped curves
+    // reach out to |u|, |v| ~ 25, which must not loosen the sides that lie on the screen)
+    auto cl = [](double x) { return std::max(-4.0, std::min(4.0, x)); };
+    const double mu = rel_margin * (cl(acc.u1) - cl(acc.u0)) + 1.0e-3, mv = rel_margin * (cl(acc.v1) - cl(acc.v0)) + 1.0e-3;
+    const double r[4] = {acc.u0 - mu, acc.v0 - mv, acc.u1 + mu, acc.v1 + mv};
+    for (double x : r) if (!std::isfinite(x)) return full_rect();
+    auto clampf = [](double x) { return (float)std::max(-3.0e38, std::min(3.0e38, x)); };
+    // round outwards
+    Rect out{std::nextafter(clampf(r[0]), -INFINITY), std::nextafter(clampf(r[1]), -INFINITY), std::nextafter(clampf(r[2]), INFINITY), std::nextafter(clampf(r[3]), INFINITY)};
+    return out;
+}
+
+}  // namespace detail
+
+// Box [bmin, bmax] in object space (cube: +-1; mesh: the root node's bounds).
+inline Rect box_rect(const rpt_object &o, int interval, const double bmin[3], const double bmax[3]) {
+    using namespace detail;
+    const DirMap m = make_map(o, interval);
+    if (!m.ok) return full_rect();
+    const D3 cam{o.stationaryCam.y, o.stationaryCam.z, o.stationaryCam.w};
+    const D3 oc{o.InvM[0].x * cam.x + o.InvM[0].y * cam.y + o.InvM[0].z * cam.z + o.InvM[0].w,
+                o.InvM[1].x * cam.x + o.InvM[1].y * cam.y + o.InvM[1].z * cam.z + o.InvM[1].w,
+                o.InvM[2].x * cam.x + o.InvM[2].y * cam.y + o.InvM[2].z * cam.z + o.InvM[2].w};
+    if (!finite3(oc)) return full_rect();
+    const double lo[3] = {bmin[0], bmin[1], bmin[2]}, hi[3] = {bmax[0], bmax[1], bmax[2]}, p[3] = {oc.x, oc.y, oc.z};
+    bool inside = true;
+    double diag2 = 0.0;
+    for (int a = 0; a < 3; a++) {
+        if (!(hi[a] >= lo[a]) || !std::isfinite(lo[a]) || !std::isfinite(hi[a])) return full_rect();
+        const double mrg = 0.05 * (hi[a] - lo[a]) + 1.0e-4;
+        inside = inside && p[a] >= lo[a] - mrg && p[a] <= hi[a] + mrg;
+        diag2 += (hi[a] - lo[a]) * (hi[a] - lo[a]);
+    }
+    if (inside) return full_rect();
+    (void)diag2;
+    // Which faces does oc see?  +1 seen, -1 hidden, 0 too close to the face's plane to say.  The outline of a convex box is
+    // made of the edges between a seen and a hidden face; only those are sampled, unless part of the box lies behind the
+    // camera (then the clip polygon's corners can come from any edge and all twelve are taken).
+    int seen_lo[3], seen_hi[3];
+    for (int a = 0; a < 3; a++) {
+        const double tol = 1.0e-6 * (hi[a] - lo[a]) + 1.0e-12;
+        seen_lo[a] = p[a] < lo[a] - tol ? 1 : (p[a] > lo[a] + tol ? -1 : 0);
+        seen_hi[a] = p[a] > hi[a] + tol ? 1 : (p[a] < hi[a] - tol ? -1 : 0);
+    }
+    const int S = m.linear ? 1 : 4;           // segments per edge: straight edges stay straight under a linear map
+    const D3 centre{0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+    if (!m.linear) {
+        // aberration: the kept region must first be shown to be a bounded patch in front of the camera (see cap_in_front);
+        // the cone K of a box is spanned by the directions to its eight corners
+        D3 corners[8];
+        for (int k = 0; k < 8; k++) corners[k] = sub(D3{(k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2]}, oc);
+        if (!m.cap_in_front(corners, 8, sub(centre, oc))) return full_rect();
+    }
+    // the eight corners are mapped once (corner k: bit 0/1/2 = x/y/z at hi); the first and the last one are pushed
+    // through F again, which is where a wrong inverse would show
+    D3 cu[8], cnd[8];
+    for (int k = 0; k < 8; k++) {
+        cu[k] = sub(D3{(k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2]}, oc);
+        if (!((k == 0 || k == 7) ? m.G_checked(cu[k], cnd[k]) : m.G(cu[k], cnd[k]))) return full_rect();
+    }
+    for (int pass = 0; pass < 2; pass++) {    // pass 0: outline edges; pass 1 (only when clipped): every edge
+        Accum acc(m);
+        bool clipped = false;
+        for (int axis = 0; axis < 3 && !acc.failed; axis++) {
+            const int b = (axis + 1) % 3, c = (axis + 2) % 3;
+            for (int corner = 0; corner < 4 && !acc.failed; corner++) {
+                const int fb = (corner & 1) ? seen_hi[b] : seen_lo[b], fc = (corner & 2) ? seen_hi[c] : seen_lo[c];
+                if (pass == 0 && fb != 0 && fc != 0 && fb == fc) continue;      // both faces seen or both hidden: not on the outline
+                double q[3];
+                q[b] = (corner & 1) ? hi[b] : lo[b];
+                q[c] = (corner & 2) ? hi[c] : lo[c];
+                D3 prev_u{};
+                bool prev_front = false;
+                const int k_lo = ((corner & 1) ? (1 << b) : 0) | ((corner & 2) ? (1 << c) : 0), k_hi = k_lo | (1 << axis);
+                for (int j = 0; j <= S; j++) {
+                    q[axis] = lo[axis] + (hi[axis] - lo[axis]) * ((double)j / S);
+                    const D3 u = j == 0 ? cu[k_lo] : (j == S ? cu[k_hi] : sub(D3{q[0], q[1], q[2]}, oc));
+                    D3 nd;
+                    bool front = false;
+                    if (j == 0 || j == S) acc.take_mapped(nd = (j == 0 ? cnd[k_lo] : cnd[k_hi]), front);
+                    else if (!acc.sample(u, nd, front, false)) break;
+                    clipped = clipped || !front;
+                    if (j > 0 && front != prev_front) acc.crossing(prev_u, u, prev_front);
+                    prev_u = u; prev_front = front;
+                }
+            }
+        }
+        if (clipped && !m.linear) return full_rect();       // cannot happen after cap_in_front; no statement if it does
+        if (pass == 0 && clipped && !acc.failed) continue;
+        return finish(acc, m.linear ? 0.002 : 0.05, m, sub(centre, oc));
+    }
+    return full_rect();
+}
+
+// Unit sphere at the object-space origin.
+inline Rect sphere_rect(const rpt_object &o, int interval) {
+    using namespace detail;
+    const DirMap m = make_map(o, interval);
+    if (!m.ok) return full_rect();
+    const D3 cam{o.stationaryCam.y, o.stationaryCam.z, o.stationaryCam.w};
+    const D3 oc{o.InvM[0].x * cam.x + o.InvM[0].y * cam.y + o.InvM[0].z * cam.z + o.InvM[0].w,
+                o.InvM[1].x * cam.x + o.InvM[1].y * cam.y + o.InvM[1].z * cam.z + o.InvM[1].w,
+                o.InvM[2].x * cam.x + o.InvM[2].y * cam.y + o.InvM[2].z * cam.z + o.InvM[2].w};
+    const double dist = len(oc);
+    const double rb = 1.02;                                    // inflated radius
+    if (!finite3(oc) || !(dist > 1.1 * rb)) return full_rect();
+    const D3 axis = mul(oc, -1.0 / dist);
+    const double sa = rb / dist, ca = std::sqrt(1.0 - sa * sa);
+    const D3 helper = std::fabs(axis.x) < 0.6 ? D3{1, 0, 0} : D3{0, 1, 0};
+    D3 e1 = cross(axis, helper);
+    e1 = mul(e1, 1.0 / len(e1));
+    const D3 e2 = cross(axis, e1);
+    const int K = 16;
+    if (!m.linear) {
+        D3 rim[K];
+        for (int k = 0; k < K; k++) {
+            const double phi = 2.0 * M_PI * k / K;
+            rim[k] = add(mul(axis, ca), mul(add(mul(e1, std::cos(phi)), mul(e2, std::sin(phi))), sa));
+        }
+        if (!m.cap_in_front(rim, K, axis)) return full_rect();
+    }
+    Accum acc(m);
+    D3 first_u{}, prev_u{};
+    bool first_front = false, prev_front = false;
+    for (int k = 0; k < K && !acc.failed; k++) {
+        const double phi = 2.0 * M_PI * k / K;
+        const D3 u = add(mul(axis, ca), mul(add(mul(e1, std::cos(phi)), mul(e2, std::sin(phi))), sa));
+        D3 nd;
+        bool front = false;
+        if (!acc.sample(u, nd, front, (k & 7) == 0)) break;
+        if (k == 0) { first_u = u; first_front = front; }
+        else if (front != prev_front) acc.crossing(prev_u, u, prev_front);
+        prev_u = u; prev_front = front;
+    }
+    if (!acc.failed && prev_front != first_front) acc.crossing(prev_u, first_u, prev_front);
+    return finish(acc, 0.04, m, axis);
+}
+
+// The rectangle of one object (type-dispatched).  root_bounds: min.xyz,max.xyz of a mesh object's root node, or null.
+inline Rect object_rect(const rpt_object &o, int interval, const float *root_bounds) {
+    if (o.type == RPT_SPHERE) return sphere_rect(o, interval);
+    if (o.type == RPT_CUBE) {
+        const double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};
+        return box_rect(o, interval, lo, hi);
+    }
+    if (o.type == RPT_MESH && root_bounds) {
+        const double lo[3] = {root_bounds[0], root_bounds[1], root_bounds[2]}, hi[3] = {root_bounds[3], root_bounds[4], root_bounds[5]};
+        return box_rect(o, interval, lo, hi);
+    }
+    return full_rect();
+}
+
+}  // namespace rptb

@@ -1,0 +1,55 @@
+"""Random scene descriptions for the fuzz tests (shared by GPU and CPU tests)."""
+import numpy as np
+
+
+def random_scene_text(rng):
+    lines = []
+    meshes = []
+    if rng.random() < 0.7:
+        meshes.append(rng.choice(["Models/pear.obj", "Models/bunny.obj", "Models/cube.obj", "Models/triangle.obj"]))
+        if rng.random() < 0.3:
+            meshes.append(rng.choice(["Models/cube.obj", "Models/pear.obj"]))
+    for m in meshes:
+        lines.append("M" + m)
+    textures = []
+    for t in ["Textures/box.jpg", "Textures/tile.jpg", "Textures/meterstick.png", "Textures/soccer.jpg"]:
+        if rng.random() < 0.4:
+            textures.append(t)
+            lines.append("T" + t)
+    n_obj = int(rng.integers(1, 9))
+    has_textured_sphere = False
+    for k in range(n_obj):
+        kind = rng.choice(["s", "c", "m"] if meshes else ["s", "c"], p=[0.3, 0.4, 0.3] if meshes else [0.45, 0.55])
+        if kind == "m":
+            mi = int(rng.integers(0, len(meshes)))
+            lines.append(f"Om{mi}")
+            scale = float(rng.choice([1.0, 2.0, 12.0])) if "bunny" in meshes[mi] else float(rng.uniform(0.5, 2.0))
+        else:
+            lines.append("O" + kind)
+            scale = float(rng.uniform(0.3, 2.5))
+        pos = rng.uniform([-6, -4, -3], [6, 4, 14])
+        if rng.random() < 0.1:
+            pos = rng.uniform(-0.3, 0.3, size=3)          # camera inside / touching the object
+        ang = float(rng.choice([0.0, rng.uniform(-3, 3)]))
+        axis = rng.normal(size=3)
+        sc = scale * rng.uniform(0.5, 1.5, size=3) if rng.random() < 0.5 else np.full(3, scale)
+        lines.append(" p" + ",".join(f"{v:.4f}" for v in [*pos, ang, *axis, *sc]))
+        lines.append(" c" + ",".join(f"{v:.3f}" for v in rng.uniform(0.05, 1.5, size=3)))
+        if textures and rng.random() < 0.5:
+            lines.append(f" t{int(rng.integers(0, len(textures)))}")
+            has_textured_sphere = has_textured_sphere or kind == "s"
+        if rng.random() < 0.3:
+            lines.append(" l1")
+        if rng.random() < 0.35:
+            v = rng.normal(size=3)
+            v = v / np.linalg.norm(v) * rng.choice([0.2, 0.6, 0.9, 0.97])
+            lines.append(" v" + ",".join(f"{c:.5f}" for c in v))
+        if rng.random() < 0.25:
+            lines.append(f" f{rng.uniform(0.5, 3):.3f},{rng.uniform(0.1, 1.5):.3f}")
+    lines.append(f"A{rng.uniform(0, 1):.3f}")
+    if rng.random() < 0.5:
+        lines.append("W" + ",".join(f"{v:.2f}" for v in rng.uniform(0.5, 6, size=3)))
+    if rng.random() < 0.25:
+        lines.append("I")
+    lines.append("R")
+    return "\n".join(lines) + "\n", has_textured_sphere

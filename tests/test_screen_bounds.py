@@ -1,0 +1,106 @@
+"""The per-object image-plane rectangles behind the default kernel's in-wave cull (csrc/rpt_screen_bounds.hpp,
+rpt_object_screen_rect) are CONSERVATIVE: every pixel whose primary ray hits an object — as the oracle renders that
+object alone — lies inside the object's rectangle.  Host code only: runs without a GPU.  (That the kernel's use of
+them never changes a frame is what the GPU parity, fuzz and culling tests check.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_ffi
+from conftest import CONFIGS, REFERENCE_SHOTS, load_config, load_reference_shot
+from relativitypathtracer_amd import Scene, _ffi
+from scene_fuzz import random_scene_text
+
+BG = np.array([0.15, 0.15, 0.25], dtype=np.float32)
+
+
+def object_rects(scene):
+    lib = _ffi.hip()
+    objs = scene.objects()
+    nodes = scene.octrees()
+    out = []
+    for i in range(len(objs)):
+        raw = objs[i:i + 1].copy()
+        root = None
+        if int(objs["type"][i]) == 2:
+            n = nodes[int(objs["meshIndex"][i])]
+            root = (C.c_float * 6)(*n["min"][:3], *n["max"][:3])
+        rect = (C.c_float * 4)()
+        assert lib.rpt_object_screen_rect(raw.ctypes.data, scene.params["interval"], root, rect) == 0
+        out.append(tuple(rect))
+    return out
+
+
+def hit_mask(scene, i, W, H):
+    """Pixels whose primary ray hits object i, from the oracle rendering that object alone."""
+    only = scene.objects()[i:i + 1].copy()
+    only["light"] = 0
+    only["textureIndex"] = -1
+    only["flashPeriod"] = 0
+    only["color"] = (1.0, 0.5, 0.25, 0.0)          # never the background colour, whatever the ambient term
+    px, rgb, _ = oracle_ffi.render(scene, W, H, objects=only)
+    bg = rgb[(rgb == rgb[0, 0]).all(axis=2)]
+    return ~((rgb == _background(scene, W, H)).all(axis=2))
+
+
+_bg_cache = {}
+
+
+def _background(scene, W, H):
+    key = tuple(scene.params["white_point"])
+    if key not in _bg_cache:
+        _, rgb, _ = oracle_ffi.render(scene, 8, 8, objects=np.zeros(0, dtype=np.uint8))
+        _bg_cache[key] = rgb[0, 0].copy()
+    return _bg_cache[key]
+
+
+def check_scene(scene, W, H, label):
+    rects = object_rects(scene)
+    ys, xs = np.mgrid[0:H, 0:W]
+    u = (xs / W - 0.5) * (W / H)
+    v = ys / H - 0.5
+    culled_something = False
+    for i, (u0, v0, u1, v1) in enumerate(rects):
+        hit = hit_mask(scene, i, W, H)
+        inside = (u >= u0) & (u <= u1) & (v >= v0) & (v <= v1)
+        bad = hit & ~inside
+        assert not bad.any(), f"{label}: object {i}: {int(bad.sum())} hit pixels outside its rectangle {(u0, v0, u1, v1)}"
+        culled_something = culled_something or not inside.all()
+    return culled_something
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_rectangles_contain_every_hit_shipped_scenes(name):
+    check_scene(load_config(name), 320, 180, name)
+
+
+@pytest.mark.parametrize("shot", ["arch2", "cube2", "cube3", "shadows4"])
+def test_rectangles_contain_every_hit_reference_camera_states(shot):
+    check_scene(load_reference_shot(shot), 256, 138, shot)
+
+
+def test_rectangles_are_tight_on_the_benchmark_scenes():
+    """bunny: the mesh and the light sphere are culled for most of the frame; shadows: the wall cube for three quarters of it,
+    the floor above its horizon."""
+    for name, min_culled_fraction in (("bunny", 0.5), ("shadows", 0.3), ("arch", 0.2)):
+        scene = load_config(name)
+        W, H = 320, 180
+        ys, xs = np.mgrid[0:H, 0:W]
+        u, v = (xs / W - 0.5) * (W / H), ys / H - 0.5
+        kept = [((u >= r[0]) & (u <= r[2]) & (v >= r[1]) & (v <= r[3])).mean() for r in object_rects(scene)]
+        assert 1.0 - float(np.mean(kept)) >= min_culled_fraction, (name, kept)
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_rectangles_contain_every_hit_random_scenes(seed):
+    rng = np.random.default_rng(7000 + seed)
+    text, _ = random_scene_text(rng)
+    scene = Scene()
+    scene.inputScene(text)
+    vel = rng.normal(size=3)
+    vel = vel / np.linalg.norm(vel) * rng.choice([0.0, 0.0, 0.5, 0.95])
+    scene.set_camera(tuple(float(c) for c in vel), float(rng.uniform(-3, 20)))
+    scene.update_objects()
+    W, H = [(160, 90), (128, 96), (200, 80)][seed % 3]
+    check_scene(scene, W, H, f"seed {seed}\n{text}")

@@ -13,10 +13,25 @@ import json
 import os
 import sys
 
-KERNELS = {"tile_bin": "rpt_tile_bin_kernel", "render": "rpt_render_kernel"}
+KERNELS = {"tile_bin": "rpt_tile_bin_kernel", "render": "rpt_render_kernel", "shade": "rpt_shade_kernel"}
 
 
-def main(src, dst):
+def build_id():
+    """What the counters were taken on: the git revision (when the snapshot has one) and the hash of librpt_hip.so —
+    bench.py quotes roofline.traffic only from a summary whose library hash equals the running library's."""
+    import hashlib
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "relativitypathtracer_amd", "librpt_hip.so")
+    ident = {"librpt_hip_sha256": hashlib.sha256(open(so, "rb").read()).hexdigest() if os.path.exists(so) else None, "git_rev": None}
+    try:
+        ident["git_rev"] = subprocess.run(["git", "-C", root, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        pass
+    return ident
+
+
+def main(src, dst, command=None):
     per = {k: collections.defaultdict(list) for k in KERNELS}
     meta = {}
     for f in sorted(glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
@@ -42,6 +57,8 @@ def main(src, dst):
     rd = sum(mean(k, "FETCH_SIZE") for k in KERNELS) * 1024 * 2
     wr = sum(mean(k, "WRITE_SIZE") for k in KERNELS) * 1024
     hit, miss = mean("render", "TCC_HIT_sum"), mean("render", "TCC_MISS_sum")
+    out["build"] = build_id()
+    out["command"] = command
     out["derived"] = {
         "hbm_read_bytes_per_launch (FETCH_SIZE KB x1024 x2 gfx950 correction)": rd,
         "hbm_write_bytes_per_launch (WRITE_SIZE KB x1024)": wr,
@@ -53,4 +70,4 @@ def main(src, dst):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
