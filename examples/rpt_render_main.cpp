@@ -78,14 +78,26 @@ int main(int argc, char **argv) {
         rpt_scene_set_paused(scene, 0);
         const auto t0 = std::chrono::steady_clock::now();
         int presented = 0;
+        // RPT_DUMP_FRAME=k RPT_DUMP_PATH=file.ppm: also write frame k (0-based) as acquire() handed it out
+        const char *dump_path = std::getenv("RPT_DUMP_PATH");
+        const int dump_frame = std::getenv("RPT_DUMP_FRAME") ? std::atoi(std::getenv("RPT_DUMP_FRAME")) : -1;
+        std::vector<unsigned char> dumped;
         for (int f = 0; f < frames && !rc; f++) {
             rpt_scene_advance_time(scene, 16);                   // render(): cameraPos.x += dt  Render.cpp:177
             rpt_scene_update_objects(scene);
             rpt_scene_get_desc(scene, &desc);
-            if (ring.submit(desc.objects, (int)desc.object_count)) presented++;   // a finished frame: drawGL() would go here
-            rc = ring.status();
+            if (void *finished = ring.acquire()) {               // frame f - in_flight, complete: drawGL() goes here,
+                presented++;                                     // BEFORE the slot is resubmitted
+                if (dump_path && f - ring.frames_in_flight() == dump_frame) {      // test hook: keep that frame's pixels
+                    dumped.resize((size_t)width * height * 16);
+                    rc = rpt_read_framebuffer(ring.slot(f % ring.frames_in_flight()), dumped.data(), dumped.size());
+                    (void)finished;
+                }
+            }
+            if (!rc) rc = ring.submit(desc.objects, (int)desc.object_count);
         }
         if (!rc && ring.drain() == nullptr) rc = ring.status() ? ring.status() : 1;
+        if (!rc && dump_path && !dumped.empty()) rc = rpt_write_ppm(dump_path, dumped.data(), width, height);
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (rc) {
             std::fprintf(stderr, "render: %s\n", ring.last_error());

@@ -11,10 +11,15 @@
  *     ring.upload(desc); ring.set_params(wp, ambient, W, H, interval);
  *     for (;;) {                                                   // render()
  *         ... Lorentz update of cpu_objects ...
- *         void *finished = ring.submit(&cpu_objects[0], (int)cpu_objects.size());   // returns at once
- *         if (finished) drawGL(finished);                          // the frame submitted N - 1 calls ago, complete
+ *         void *finished = ring.acquire();                         // the frame submitted N calls ago, complete (or nullptr)
+ *         if (finished) drawGL(finished);                          // consume it BEFORE its slot is given the next frame
+ *         ring.submit(&cpu_objects[0], (int)cpu_objects.size());   // returns at once; overwrites what acquire() returned
  *     }
  *     void *last = ring.drain();                                   // wait for everything; the newest frame
+ *
+ * acquire() and submit() are two calls on purpose: the framebuffer acquire() hands out belongs to the slot that the next
+ * submit() renders into, so the host must be done with it (drawn, copied, or its own stream made to wait) before it
+ * submits.  (An earlier revision returned the pointer FROM submit(), i.e. after the overwriting launch was enqueued.)
  *
  * Every call returns/propagates the library's status through status(); a failed call leaves the ring usable.
  */
@@ -64,22 +69,24 @@ public:
         }
         return status_;
     }
-    /* Render.cpp:202-205 without the finish: refresh Object[] and enqueue the frame in the next slot.  Returns the
-     * framebuffer (device pointer, 16 B/pixel) of the frame that slot held before — complete — or nullptr while
-     * the ring is still filling or after an error. */
-    void *submit(const void *objects, int count) {
-        if (slots_.empty()) return nullptr;
+    /* Wait for the frame the NEXT submit() will overwrite — the oldest one in flight — and return its framebuffer
+     * (device pointer, 16 B/pixel), complete; nullptr while the ring is still filling or after an error.  The pointer
+     * is valid until the next submit(). */
+    void *acquire() {
+        if (slots_.empty() || submitted_ < slots_.size()) return nullptr;
+        if (!check(next_, rpt_sync(slots_[next_]))) return nullptr;
+        return rpt_output_ptr(slots_[next_]);
+    }
+    /* Render.cpp:202-205 without the finish: refresh Object[] and enqueue the frame in the next slot; returns the
+     * status.  The slot's previous frame (what acquire() returned) is overwritten. */
+    int submit(const void *objects, int count) {
+        if (slots_.empty()) return status_;
         const size_t k = next_;
-        void *finished = nullptr;
-        if (submitted_ >= slots_.size()) {                       // the slot holds an older frame: wait for it, hand it out
-            if (!check(k, rpt_sync(slots_[k]))) return nullptr;
-            finished = rpt_output_ptr(slots_[k]);
-        }
-        if (!check(k, rpt_set_objects(slots_[k], objects, count))) return nullptr;
-        if (!check(k, rpt_render_async(slots_[k]))) return nullptr;
+        if (!check(k, rpt_set_objects(slots_[k], objects, count))) return status_;
+        if (!check(k, rpt_render_async(slots_[k]))) return status_;
         next_ = (next_ + 1) % slots_.size();
         submitted_++;
-        return finished;
+        return status_;
     }
     /* Wait for every frame in flight; returns the framebuffer of the newest one (nullptr if none was submitted). */
     void *drain() {

@@ -892,17 +892,19 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
     const int local_row = tile_row * RPT_TILE_ROWS + row_in_tile;
     const int global_tile = (tile_row >> a.run_log2) * a.tile_step + a.first_tile + (tile_row & ((1 << a.run_log2) - 1));
     const int y_coord = global_tile * RPT_TILE_ROWS + row_in_tile;
+    // the wave's object mask comes from a __ballot over ALL 64 lanes (lane i answers for object i), so it is formed
+    // before the lanes of a partial tile leave
+    unsigned long long object_mask = ~0ull;
+    if (V >= 20) object_mask = wave_object_mask(a, (int)blockIdx.x * 32 + wave * 8, global_tile * RPT_TILE_ROWS);
     if (x_coord >= a.width || y_coord >= a.height) return;   // the reference has no guard (UB)
 
     f3 color;
     f3 mapped = mk3(a.bg_mapped[0], a.bg_mapped[1], a.bg_mapped[2]);
     uint32_t packed = a.bg_packed;
-    unsigned long long object_mask = ~0ull;
     if (V == 10 || V == 11 || V == 12) {   // per-tile object mask of the prepass
         const int tile = __builtin_amdgcn_readfirstlane(tile_row * a.tiles_x + (int)blockIdx.x * 4 + wave);
         object_mask = a.tile_masks[tile];
     }
-    if (V >= 20) object_mask = wave_object_mask(a, (int)blockIdx.x * 32 + wave * 8, global_tile * RPT_TILE_ROWS);
     const bool masked = V == 10 || V == 11 || V == 12 || V >= 20;
     if (!masked || object_mask != 0 || a.object_count > 64) {
         const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);

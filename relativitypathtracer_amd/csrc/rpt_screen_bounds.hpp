@@ -12,10 +12,14 @@
 // bounded by G(boundary of K), G = F^-1:  the silhouette curve of B is sampled, every sample is mapped to a camera
 // direction and CHECKED by pushing it through F again with the very matrices the kernel uses, and the rectangle is the
 // bounding box of the samples' image-plane positions (plane z = 0.5: u = x/2z, v = y/2z), grown by a margin that covers
-// the curve between samples.  Parts of the curve behind the camera are clipped at the cone nd.z = EPS |nd| (far outside
-// any screen); every doubtful case — origin inside or near B, non-finite numbers, a failed check, a clipped region that
-// spreads over more than a third of the horizon — returns the full plane.  Arithmetic here may be approximate: it only
-// decides which exact tests are skipped, and a skipped test is one the reference would have failed for every pixel.
+// the curve between samples.  The region is cut off at the cone nd.z = EPS |nd| ("the horizon": a circle of radius ~25 on
+// the plane, far outside any screen): where the outline crosses it the crossing point is located, and the part of the
+// horizon circle that lies INSIDE the region — decided for sampled horizon directions by sending them through F and
+// asking whether that object-space ray meets B — is added to the box, so a floor under the camera or an object half
+// behind it gets a rectangle that is open exactly on the sides where it runs off to infinity.  What is boxed is then the
+// complete boundary of a bounded planar region, so no inside/outside question is left open.  Every doubtful case — origin
+// inside or near B, non-finite numbers, a failed check — returns the full plane.  Arithmetic here may be approximate: it
+// only decides which exact tests are skipped, and a skipped test is one the reference would have failed for every pixel.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -86,67 +90,6 @@ struct DirMap {
         nd = {c[1], c[2], c[3]};
         return c[0] < 0.0 && finite3(nd) && len(nd) > 0.0;
     }
-    // rest-frame direction (Lorentz * (interval, nd))[1..3] -> camera direction, interval = -1 only
-    bool G_rest(D3 r, D3 &nd) const {
-        const double rl = len(r);
-        const double k[4] = {-rl, r.x, r.y, r.z};
-        double c[4];
-        for (int i = 0; i < 4; i++) c[i] = Linv[i][0] * k[0] + Linv[i][1] * k[1] + Linv[i][2] * k[2] + Linv[i][3] * k[3];
-        nd = {c[1], c[2], c[3]};
-        return c[0] < 0.0 && finite3(nd) && len(nd) > 0.0;
-    }
-    D3 to_rest(D3 u) const {
-        return {M3[0][0] * u.x + M3[0][1] * u.y + M3[0][2] * u.z, M3[1][0] * u.x + M3[1][1] * u.y + M3[1][2] * u.z,
-                M3[2][0] * u.x + M3[2][1] * u.y + M3[2][2] * u.z};
-    }
-    // Aberration case (interval = -1, G not linear).  The object-space directions `dirs` span the cone K of rays that can
-    // meet the bounding shape.  In the object's rest frame K lies inside the circular cone around `axis_obj` of half-angle
-    // beta' = the largest angle to any of `dirs` (they are K's extreme rays, or samples of them; a margin is added).  The
-    // camera sees rest-frame directions through a Lorentz transformation of null vectors, i.e. a Moebius map of the
-    // direction sphere, and those map circles to circles: the circular cone becomes a spherical cap {n.c >= cos(beta)} that
-    // contains every camera direction to be kept.  True when that cap is small (< 80 deg) and lies wholly in front of the
-    // camera's clip cone — then the kept region is a bounded patch of the image plane and the bounding box of its sampled
-    // outline (plus margin) contains it.  False = no statement, use the full plane.
-    bool cap_in_front(const D3 *dirs, int n, D3 axis_obj) const {
-        D3 a = to_rest(axis_obj);
-        const double la = len(a);
-        if (!(la > 0.0)) return false;
-        a = mul(a, 1.0 / la);
-        double cmin = 1.0;
-        for (int i = 0; i < n; i++) {
-            const D3 r = to_rest(dirs[i]);
-            const double lr = len(r);
-            if (!(lr > 0.0)) return false;
-            cmin = std::min(cmin, dot(a, r) / lr);
-        }
-        const double beta_rest = std::acos(std::max(-1.0, std::min(1.0, cmin))) * 1.03 + 0.01;
-        if (!(beta_rest < 1.45)) return false;
-        const D3 helper = std::fabs(a.x) < 0.6 ? D3{1, 0, 0} : D3{0, 1, 0};
-        D3 e1 = cross(a, helper);
-        e1 = mul(e1, 1.0 / len(e1));
-        const D3 e2 = cross(a, e1);
-        D3 p[6], pc;
-        const double cbr = std::cos(beta_rest), sbr = std::sin(beta_rest);
-        static const double C6[6] = {1.0, 0.5, -0.5, -1.0, -0.5, 0.5}, S6[6] = {0.0, 0.8660254037844386, 0.8660254037844386, 0.0, -0.8660254037844386, -0.8660254037844386};
-        for (int i = 0; i < 6; i++) {
-            const D3 r = add(mul(a, cbr), mul(add(mul(e1, C6[i]), mul(e2, S6[i])), sbr));
-            if (!G_rest(r, p[i])) return false;
-            p[i] = mul(p[i], 1.0 / len(p[i]));
-        }
-        if (!G_rest(a, pc)) return false;
-        pc = mul(pc, 1.0 / len(pc));
-        D3 c = cross(sub(p[2], p[0]), sub(p[4], p[0]));
-        const double lc = len(c);
-        if (!(lc > 1.0e-12)) return false;
-        c = mul(c, 1.0 / lc);
-        if (dot(c, pc) < dot(c, p[0])) c = mul(c, -1.0);
-        const double cb = dot(c, p[0]);
-        for (int i = 0; i < 6; i++) if (std::fabs(dot(c, p[i]) - cb) > 1.0e-6) return false;      // not a circle: something is off
-        if (!(dot(c, pc) > cb)) return false;
-        const double beta = std::acos(std::max(-1.0, std::min(1.0, cb)));
-        const double tilt = std::acos(std::max(-1.0, std::min(1.0, c.z)));
-        return beta < 1.40 && tilt + beta < std::acos(EPS_FRONT) - 0.05;
-    }
     // G, verified through F: the angle between F(G(u)) and u must vanish
     bool G_checked(D3 u, D3 &nd) const {
         if (!G(u, nd)) return false;
@@ -193,7 +136,6 @@ struct Accum {
     const DirMap &m;
     double u0 = 1e300, v0 = 1e300, u1 = -1e300, v1 = -1e300;
     bool failed = false, any_front = false, any_near_behind = false;
-    double crossing_angles[32];
     int n_crossings = 0;
     explicit Accum(const DirMap &map) : m(map) {}
 
@@ -231,35 +173,47 @@ struct Accum {
         if (!m.G_checked(front_a ? lo : hi, nd) || !(nd.z > 0.0)) { failed = true; return; }
         take(nd);
         any_front = true;
-        if (n_crossings >= 32) { failed = true; return; }
-        crossing_angles[n_crossings++] = std::atan2(nd.y, nd.x);
+        n_crossings++;
+        if (!m.linear) {
+            // a curved outline runs off towards the horizon along an asymptote and may swing past both of its end points on
+            // the way: follow it from the last sample in front (ua or ub) to the crossing in steps that halve the distance
+            const D3 cross_u = front_a ? lo : hi, from_u = front_a ? ua : ub;
+            double w = 0.5;
+            for (int k = 0; k < 10; k++, w *= 0.5) {
+                const D3 u = add(mul(cross_u, 1.0 - w), mul(from_u, w));
+                D3 n2;
+                if (!m.G(u, n2)) { failed = true; return; }
+                if (frontness(n2) > 0.0) take(n2);
+            }
+        }
     }
-    // after all samples: does the clipped part spread over too much of the horizon to be bounded by its end points?
-    bool horizon_span_too_wide() const {
-        if (n_crossings < 2) return false;
-        double a[32];
-        std::copy(crossing_angles, crossing_angles + n_crossings, a);
-        std::sort(a, a + n_crossings);
-        double gap = a[0] + 2.0 * M_PI - a[n_crossings - 1];
-        for (int i = 1; i < n_crossings; i++) gap = std::max(gap, a[i] - a[i - 1]);
-        return 2.0 * M_PI - gap > 2.0 * M_PI / 3.0;
+    // The horizon circle nd.z = EPS |nd|: which part of it lies inside the kept region?  `inside(d)` answers for an
+    // object-space direction d (does the ray from oc along d meet the inflated bounding shape).  n directions are tried;
+    // a member also claims its two neighbours, which covers the arc between samples.  Returns the number of members.
+    template <class Inside>
+    int horizon(int n, Inside inside) {
+        bool member[64];
+        if (n > 64) n = 64;
+        const double s = std::sqrt(1.0 - EPS_FRONT * EPS_FRONT);
+        int count = 0;
+        for (int j = 0; j < n; j++) {
+            const double phi = 2.0 * M_PI * j / n;
+            member[j] = inside(m.F(D3{s * std::cos(phi), s * std::sin(phi), EPS_FRONT}));
+            count += member[j];
+        }
+        for (int j = 0; j < n && count; j++) {
+            if (!(member[j] || member[(j + 1) % n] || member[(j + n - 1) % n])) continue;
+            const double phi = 2.0 * M_PI * j / n;
+            take(D3{s * std::cos(phi), s * std::sin(phi), EPS_FRONT});
+            any_front = true;
+        }
+        return count;
     }
 };
 
-inline Rect finish(const Accum &acc, double rel_margin, const DirMap &m, D3 centre_dir) {
+inline Rect finish(const Accum &acc, double rel_margin) {
     if (acc.failed) return full_rect();
     if (!acc.any_front) return acc.any_near_behind ? full_rect() : empty_rect();      // wholly (and well) behind the camera
-    if (acc.horizon_span_too_wide()) return full_rect();
-    // the inside of the sampled curve must be the bounded side: the direction to the shape's centre, when it is in front
-    // of the camera, has to land inside the box
-    D3 ndc;
-    if (!m.G_checked(centre_dir, ndc)) return full_rect();
-    if (Accum::frontness(ndc) > 0.0) {
-        const double u = 0.5 * ndc.x / ndc.z, v = 0.5 * ndc.y / ndc.z;
-        if (!(u >= acc.u0 && u <= acc.u1 && v >= acc.v0 && v <= acc.v1)) return full_rect();
-    } else if (!m.linear) {
-        return full_rect();
-    }
     // margins relative to the part of the box that can matter (screens reach |u| <= aspect/2, |v| <= 1/2; clipped curves
     // reach out to |u|, |v| ~ 25, which must not loosen the sides that lie on the screen)
     auto cl = [](double x) { return std::max(-4.0, std::min(4.0, x)); };
@@ -270,6 +224,23 @@ inline Rect finish(const Accum &acc, double rel_margin, const DirMap &m, D3 cent
     // round outwards
     Rect out{std::nextafter(clampf(r[0]), -INFINITY), std::nextafter(clampf(r[1]), -INFINITY), std::nextafter(clampf(r[2]), INFINITY), std::nextafter(clampf(r[3]), INFINITY)};
     return out;
+}
+
+// does the ray from `oc` along `d` meet the box [lo, hi] (already inflated)?  Slab test; NaN -> true.
+inline bool ray_meets_box(const double oc[3], D3 d, const double lo[3], const double hi[3]) {
+    const double dd[3] = {d.x, d.y, d.z};
+    double t0 = 0.0, t1 = 1.0e300;
+    for (int a = 0; a < 3; a++) {
+        if (dd[a] == 0.0) {
+            if (oc[a] < lo[a] || oc[a] > hi[a]) return false;
+            continue;
+        }
+        double ta = (lo[a] - oc[a]) / dd[a], tb = (hi[a] - oc[a]) / dd[a];
+        if (ta > tb) std::swap(ta, tb);
+        t0 = std::max(t0, ta);
+        t1 = std::min(t1, tb);
+    }
+    return !(t0 > t1);
 }
 
 }  // namespace detail
@@ -296,23 +267,16 @@ inline Rect box_rect(const rpt_object &o, int interval, const double bmin[3], co
     if (inside) return full_rect();
     (void)diag2;
     // Which faces does oc see?  +1 seen, -1 hidden, 0 too close to the face's plane to say.  The outline of a convex box is
-    // made of the edges between a seen and a hidden face; only those are sampled, unless part of the box lies behind the
-    // camera (then the clip polygon's corners can come from any edge and all twelve are taken).
+    // made of the edges between a seen and a hidden face; only those are sampled (edges between two seen or two hidden
+    // faces lie inside the outline: taking or leaving them changes nothing).
     int seen_lo[3], seen_hi[3];
     for (int a = 0; a < 3; a++) {
         const double tol = 1.0e-6 * (hi[a] - lo[a]) + 1.0e-12;
         seen_lo[a] = p[a] < lo[a] - tol ? 1 : (p[a] > lo[a] + tol ? -1 : 0);
         seen_hi[a] = p[a] > hi[a] + tol ? 1 : (p[a] < hi[a] - tol ? -1 : 0);
     }
-    const int S = m.linear ? 1 : 4;           // segments per edge: straight edges stay straight under a linear map
-    const D3 centre{0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
-    if (!m.linear) {
-        // aberration: the kept region must first be shown to be a bounded patch in front of the camera (see cap_in_front);
-        // the cone K of a box is spanned by the directions to its eight corners
-        D3 corners[8];
-        for (int k = 0; k < 8; k++) corners[k] = sub(D3{(k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2]}, oc);
-        if (!m.cap_in_front(corners, 8, sub(centre, oc))) return full_rect();
-    }
+    const int S = m.linear ? 1 : 16;          // segments per edge: straight edges stay straight under a linear map; under
+                                              // aberration they become conic arcs, sampled densely (and see crossing())
     // the eight corners are mapped once (corner k: bit 0/1/2 = x/y/z at hi); the first and the last one are pushed
     // through F again, which is where a wrong inverse would show
     D3 cu[8], cnd[8];
@@ -320,38 +284,44 @@ inline Rect box_rect(const rpt_object &o, int interval, const double bmin[3], co
         cu[k] = sub(D3{(k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2]}, oc);
         if (!((k == 0 || k == 7) ? m.G_checked(cu[k], cnd[k]) : m.G(cu[k], cnd[k]))) return full_rect();
     }
-    for (int pass = 0; pass < 2; pass++) {    // pass 0: outline edges; pass 1 (only when clipped): every edge
-        Accum acc(m);
-        bool clipped = false;
-        for (int axis = 0; axis < 3 && !acc.failed; axis++) {
-            const int b = (axis + 1) % 3, c = (axis + 2) % 3;
-            for (int corner = 0; corner < 4 && !acc.failed; corner++) {
-                const int fb = (corner & 1) ? seen_hi[b] : seen_lo[b], fc = (corner & 2) ? seen_hi[c] : seen_lo[c];
-                if (pass == 0 && fb != 0 && fc != 0 && fb == fc) continue;      // both faces seen or both hidden: not on the outline
-                double q[3];
-                q[b] = (corner & 1) ? hi[b] : lo[b];
-                q[c] = (corner & 2) ? hi[c] : lo[c];
-                D3 prev_u{};
-                bool prev_front = false;
-                const int k_lo = ((corner & 1) ? (1 << b) : 0) | ((corner & 2) ? (1 << c) : 0), k_hi = k_lo | (1 << axis);
-                for (int j = 0; j <= S; j++) {
-                    q[axis] = lo[axis] + (hi[axis] - lo[axis]) * ((double)j / S);
-                    const D3 u = j == 0 ? cu[k_lo] : (j == S ? cu[k_hi] : sub(D3{q[0], q[1], q[2]}, oc));
-                    D3 nd;
-                    bool front = false;
-                    if (j == 0 || j == S) acc.take_mapped(nd = (j == 0 ? cnd[k_lo] : cnd[k_hi]), front);
-                    else if (!acc.sample(u, nd, front, false)) break;
-                    clipped = clipped || !front;
-                    if (j > 0 && front != prev_front) acc.crossing(prev_u, u, prev_front);
-                    prev_u = u; prev_front = front;
-                }
+    Accum acc(m);
+    bool clipped = false;
+    for (int axis = 0; axis < 3 && !acc.failed; axis++) {
+        const int b = (axis + 1) % 3, c = (axis + 2) % 3;
+        for (int corner = 0; corner < 4 && !acc.failed; corner++) {
+            const int fb = (corner & 1) ? seen_hi[b] : seen_lo[b], fc = (corner & 2) ? seen_hi[c] : seen_lo[c];
+            if (fb != 0 && fc != 0 && fb == fc) continue;      // both faces seen or both hidden: not on the outline
+            double q[3];
+            q[b] = (corner & 1) ? hi[b] : lo[b];
+            q[c] = (corner & 2) ? hi[c] : lo[c];
+            D3 prev_u{};
+            bool prev_front = false;
+            const int k_lo = ((corner & 1) ? (1 << b) : 0) | ((corner & 2) ? (1 << c) : 0), k_hi = k_lo | (1 << axis);
+            for (int j = 0; j <= S; j++) {
+                q[axis] = lo[axis] + (hi[axis] - lo[axis]) * ((double)j / S);
+                const D3 u = j == 0 ? cu[k_lo] : (j == S ? cu[k_hi] : sub(D3{q[0], q[1], q[2]}, oc));
+                D3 nd;
+                bool front = false;
+                if (j == 0 || j == S) acc.take_mapped(nd = (j == 0 ? cnd[k_lo] : cnd[k_hi]), front);
+                else if (!acc.sample(u, nd, front, false)) break;
+                clipped = clipped || !front;
+                if (j > 0 && front != prev_front) acc.crossing(prev_u, u, prev_front);
+                prev_u = u; prev_front = front;
             }
         }
-        if (clipped && !m.linear) return full_rect();       // cannot happen after cap_in_front; no statement if it does
-        if (pass == 0 && clipped && !acc.failed) continue;
-        return finish(acc, m.linear ? 0.002 : 0.05, m, sub(centre, oc));
     }
-    return full_rect();
+    if (acc.failed) return full_rect();
+    // the horizon: coarse when the whole outline is in front of the camera (it then only guards against a region that
+    // wraps around behind the camera, which strong aberration can produce), fine when the outline is clipped
+    double blo[3], bhi[3];
+    for (int a = 0; a < 3; a++) { const double g = 0.05 * (hi[a] - lo[a]) + 1.0e-4; blo[a] = lo[a] - g; bhi[a] = hi[a] + g; }
+    auto inside_box = [&](D3 d) { return !finite3(d) || ray_meets_box(p, d, blo, bhi); };
+    if (!clipped) {
+        if (acc.horizon(8, inside_box) > 0) acc.horizon(32, inside_box);
+    } else {
+        acc.horizon(32, inside_box);
+    }
+    return finish(acc, m.linear ? 0.002 : 0.05);
 }
 
 // Unit sphere at the object-space origin.
@@ -373,15 +343,8 @@ inline Rect sphere_rect(const rpt_object &o, int interval) {
     e1 = mul(e1, 1.0 / len(e1));
     const D3 e2 = cross(axis, e1);
     const int K = 16;
-    if (!m.linear) {
-        D3 rim[K];
-        for (int k = 0; k < K; k++) {
-            const double phi = 2.0 * M_PI * k / K;
-            rim[k] = add(mul(axis, ca), mul(add(mul(e1, std::cos(phi)), mul(e2, std::sin(phi))), sa));
-        }
-        if (!m.cap_in_front(rim, K, axis)) return full_rect();
-    }
     Accum acc(m);
+    bool clipped = false;
     D3 first_u{}, prev_u{};
     bool first_front = false, prev_front = false;
     for (int k = 0; k < K && !acc.failed; k++) {
@@ -390,12 +353,24 @@ inline Rect sphere_rect(const rpt_object &o, int interval) {
         D3 nd;
         bool front = false;
         if (!acc.sample(u, nd, front, (k & 7) == 0)) break;
+        clipped = clipped || !front;
         if (k == 0) { first_u = u; first_front = front; }
         else if (front != prev_front) acc.crossing(prev_u, u, prev_front);
         prev_u = u; prev_front = front;
     }
     if (!acc.failed && prev_front != first_front) acc.crossing(prev_u, first_u, prev_front);
-    return finish(acc, 0.04, m, axis);
+    if (acc.failed) return full_rect();
+    const double cos_in = std::cos(std::min(1.5, std::asin(sa) * 1.05 + 0.01));      // the cone, a little wider
+    auto inside_cone = [&](D3 d) {
+        const double l = len(d);
+        return !finite3(d) || !(l > 0.0) || dot(d, axis) >= cos_in * l;
+    };
+    if (!clipped) {
+        if (acc.horizon(8, inside_cone) > 0) acc.horizon(32, inside_cone);
+    } else {
+        acc.horizon(32, inside_cone);
+    }
+    return finish(acc, 0.04);
 }
 
 // The rectangle of one object (type-dispatched).  root_bounds: min.xyz,max.xyz of a mesh object's root node, or null.

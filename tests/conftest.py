@@ -16,12 +16,14 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def _built_libraries():
-    """Build the in-tree libraries once if they are missing (hipcc cross-compiles without a GPU)."""
-    pkg = os.path.join(ROOT, "relativitypathtracer_amd")
-    need = [os.path.join(pkg, "librpt_scene.so"), os.path.join(pkg, "librpt_hip.so"),
-            os.path.join(ROOT, "oracle", "librpt_oracle.so")]
-    if not all(os.path.exists(p) for p in need):
-        subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py")], check=True, cwd=ROOT)
+    """Bring the in-tree libraries up to date before any test loads them: `make` is a no-op when they are newer than
+    their sources, and a stale .so (they are git-ignored) would let kernel and oracle pass on old code.  hipcc
+    cross-compiles without a GPU.  A box without the toolchain (none is planned) keeps what travelled with the snapshot."""
+    import shutil
+    if shutil.which("make"):
+        for d in (os.path.join(ROOT, "relativitypathtracer_amd", "csrc"), os.path.join(ROOT, "oracle")):
+            p = subprocess.run(["make", "-C", d, "all"], capture_output=True, text=True)
+            assert p.returncode == 0, f"make -C {d} failed:\n{p.stdout[-2000:]}\n{p.stderr[-2000:]}"
     yield
 
 

@@ -84,6 +84,36 @@ def test_example_host_frames_in_flight(tmp_path):
     assert np.array_equal(img, opx["rgba"].reshape(H, W, 4)[::-1, :, :3])
 
 
+@pytest.mark.gpu
+def test_frame_ring_acquire_hands_out_the_frame_of_n_submits_ago(tmp_path):
+    """rpt::FrameRing::acquire() returns the OLDEST frame in flight, complete and not yet overwritten: the example host
+    copies frame 17 of 40 back right after acquire() (while two newer frames are in flight) and the pixels are the
+    oracle's frame 17 — not frame 20, which the same slot receives in the following submit()."""
+    import oracle_ffi
+    from relativitypathtracer_amd import Scene
+    exe = build(tmp_path)
+    out, dump = tmp_path / "anim.ppm", tmp_path / "frame17.ppm"
+    W, H, frames, k = 320, 184, 40, 17
+    with open(os.path.join(ASSETS, "Scenes", "shadows.txt")) as f:
+        p = subprocess.run([exe, str(W), str(H), str(out), "0", "0", "0", "16", str(frames), "3"], stdin=f, capture_output=True,
+                           text=True, env={**os.environ, "RPT_ASSETS": ASSETS, "RPT_DUMP_FRAME": str(k), "RPT_DUMP_PATH": str(dump)})
+    assert p.returncode == 0, p.stderr
+    header = f"P6\n{W} {H}\n255\n".encode()
+    img = np.frombuffer(dump.read_bytes()[len(header):], np.uint8).reshape(H, W, 3)
+    frames_by_clock = {}
+    for n in (k, k + 3):
+        s = Scene.from_file("shadows")
+        s.set_camera((0, 0, 0), 16.0)
+        s.set_paused(False)
+        for _ in range(n + 1):
+            s.advance_time(16)
+        s.update_objects()
+        opx, _, _ = oracle_ffi.render(s, W, H, want_rgb=False)
+        frames_by_clock[n] = opx["rgba"].reshape(H, W, 4)[::-1, :, :3]
+    assert np.array_equal(img, frames_by_clock[k])
+    assert not np.array_equal(frames_by_clock[k], frames_by_clock[k + 3])
+
+
 def build_multi_gpu(tmp_path):
     exe = str(tmp_path / "rpt_multi_gpu")
     cmd = ["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", f"-I{ROOT}/include", "-I/opt/rocm/include",
