@@ -216,7 +216,7 @@ inline Rect finish(const Accum &acc, double rel_margin) {
     if (!acc.any_front) return acc.any_near_behind ? full_rect() : empty_rect();      // wholly (and well) behind the camera
     // margins relative to the part of the box that can matter (screens reach |u| <= aspect/2, |v| <= 1/2; clipped curves
     // reach out to |u|, |v| ~ 25, which must not loosen the sides that lie on the screen)
-    auto cl = [](double x) { return std::max(-4.0, std::min(4.0, x)); };
+    auto cl = [](double x) { return std::max(-1.5, std::min(1.5, x)); };
     const double mu = rel_margin * (cl(acc.u1) - cl(acc.u0)) + 1.0e-3, mv = rel_margin * (cl(acc.v1) - cl(acc.v0)) + 1.0e-3;
     const double r[4] = {acc.u0 - mu, acc.v0 - mv, acc.u1 + mu, acc.v1 + mv};
     for (double x : r) if (!std::isfinite(x)) return full_rect();
@@ -321,7 +321,7 @@ inline Rect box_rect(const rpt_object &o, int interval, const double bmin[3], co
     } else {
         acc.horizon(32, inside_box);
     }
-    return finish(acc, m.linear ? 0.002 : 0.05);
+    return finish(acc, m.linear ? 0.002 : 0.015);
 }
 
 // Unit sphere at the object-space origin.
@@ -342,7 +342,7 @@ inline Rect sphere_rect(const rpt_object &o, int interval) {
     D3 e1 = cross(axis, helper);
     e1 = mul(e1, 1.0 / len(e1));
     const D3 e2 = cross(axis, e1);
-    const int K = 16;
+    const int K = m.linear ? 16 : 32;      // samples on the tangent cone's rim
     Accum acc(m);
     bool clipped = false;
     D3 first_u{}, prev_u{};

@@ -104,3 +104,20 @@ def test_rectangles_contain_every_hit_random_scenes(seed):
     scene.update_objects()
     W, H = [(160, 90), (128, 96), (200, 80)][seed % 3]
     check_scene(scene, W, H, f"seed {seed}\n{text}")
+
+
+def test_rectangles_contain_every_hit_shipped_scenes_random_cameras():
+    """Every shipped scene from cameras at 0, 0.3c, 0.9c and 0.99c in random directions at random times (objects in front
+    of, around and behind the camera; strong aberration)."""
+    rng = np.random.default_rng(2024)
+    scenes = ["shadows", "bunny", "arch", "cubes", "rulers", "ladder_paradox", "soccer", "cube"]
+    for trial in range(64):
+        name = scenes[trial % len(scenes)]
+        s = Scene.from_file(name)
+        v = rng.normal(size=3)
+        v = v / np.linalg.norm(v) * rng.choice([0.0, 0.3, 0.9, 0.99])
+        t = float(rng.uniform(-5, 25))
+        s.set_camera(tuple(float(c) for c in v), t)
+        s.update_objects()
+        W, H = [(240, 135), (166, 38), (160, 120)][trial % 3]
+        check_scene(s, W, H, f"trial {trial} {name} {W}x{H} v={v} t={t}")
