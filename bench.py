@@ -19,6 +19,10 @@ one at a time (the reference's blocking runKernel) are timed right after and rep
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (bare: starts the N ranks itself as child processes through the same launcher,
+                                         before anything in this process touches the GPU, and relays rank 0's line)
+    python bench.py --gpus 2 --dry-run  (launch plumbing only — rendezvous, barriers, the max-over-ranks reduction, the
+                                         line's keys — over gloo without touching a device: runs on a box with no GPU)
 
 Rank 0 prints ONE JSON line.  Beside the contract's keys: `kernel_ms` (mean HIP-event duration of a render launch in
 the timed region), `one_frame_at_a_time` (the same frames submitted and waited for one by one: latency), `roofline`
@@ -38,6 +42,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+DEFAULT_KERNEL = "rpt_render_kernel_ballot_w5"   # what variant 0 launches (csrc/rpt_api.hip)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md): the contract roofline for this path
 
 WORKLOADS = {
@@ -107,6 +112,92 @@ def cpu_baseline(scene, width, height, budget_s=12.0):
     }
 
 
+def library_sha256():
+    """Identity of the running render library: what a PMC summary must have been taken on to be quoted."""
+    import hashlib
+    so = os.path.join(ROOT, "relativitypathtracer_amd", "librpt_hip.so")
+    try:
+        with open(so, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        return None
+
+
+def measured_traffic(workload, width, height):
+    """HBM bytes per frame from a committed rocprofv3 PMC summary (tools/profile.sh + tools/pmc_summary.py: separate
+    --pmc passes, FETCH_SIZE doubled on gfx950, WRITE_SIZE as is) — ONLY if that summary was taken on this very build of
+    librpt_hip.so (recorded hash == running hash); otherwise None: counters cannot be collected from inside this process,
+    and a number from another build would be stale."""
+    import glob
+    mine = library_sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_{width}x{height}_pmc_summary.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if mine and d.get("build", {}).get("librpt_hip_sha256") == mine:
+                return int(sum(v for k, v in d["derived"].items() if k.startswith("hbm_"))), os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
+def spread(values):
+    """mean / median / min / max of a list of per-frame times (ms)."""
+    v = sorted(float(x) for x in values)
+    if not v:
+        return None
+    mid = len(v) // 2
+    med = v[mid] if len(v) % 2 else 0.5 * (v[mid - 1] + v[mid])
+    return {"mean": round(sum(v) / len(v), 4), "median": round(med, 4), "min": round(v[0], 4), "max": round(v[-1], 4), "frames": len(v)}
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as CHILD processes through
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and pass rank 0's output through.  Nothing in
+    this process has touched the GPU or imported torch.cuda state at this point, and nothing is exec'd."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, RPT_BENCH_CHILD="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args):
+    """The contract's control flow without a device: one process per rank, gloo rendezvous, barrier-bracketed region,
+    max over ranks, rank 0 prints the line (value null, "dry_run": true)."""
+    import torch
+    import torch.distributed as td
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        td.init_process_group("gloo")
+    if world > 1:
+        td.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if world > 1:
+        td.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "Mrays/s (primary rays) on Scenes/bunny.txt at 3840x2160", "value": None, "unit": "Mrays/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": f"Scenes/{args.workload}.txt {args.width}x{args.height}"},
+                          "comm": {"backend": "gloo" if world > 1 else None, "world_size": world,
+                                   "ranks_in_group": td.get_world_size() if world > 1 else 1}}), flush=True)
+    if world > 1:
+        td.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,7 +215,13 @@ def main():
     ap.add_argument("--check", action="store_true", help="after timing, compare rank 0's framebuffer with the oracle on a few row bands")
     ap.add_argument("--gather", default=os.environ.get("RPT_GATHER", "plane3"), choices=["plane3", "plane4"],
                     help="what is gathered with N>1: the colour plane at 3 B/pixel (constant alpha byte dropped) or at 4 B/pixel as rendered")
+    ap.add_argument("--dry-run", action="store_true", help="launch plumbing only (gloo, no device work): see the module docstring")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))     # bare `python bench.py --gpus N`: this process only launches and relays
+    if args.dry_run:
+        return dry_run(args)
 
     import numpy as np
     import torch
@@ -136,10 +233,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n = args.gpus
-    if world != n:
-        if world == 1 and n > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
-        n = world
+    n = world                                        # the launcher's word: one rank per GPU
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     if local_rank >= torch.cuda.device_count():      # launcher narrowed the visible devices to one per process
@@ -150,7 +244,11 @@ def main():
         import torch.distributed as td
         if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
             os.environ["NCCL_DEBUG"] = "WARN"       # RCCL's version banner goes to stdout; this program prints ONE line there
-        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("RPT_BENCH_BACKEND", "nccl")     # "gloo": rehearse N ranks on ONE GPU (RCCL refuses two ranks per device)
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            td.init_process_group(backend)
 
     W, H = args.width, args.height
     scene_name, vel, t = WORKLOADS[args.workload]
@@ -214,8 +312,13 @@ def main():
 
     import ctypes as C
 
+    def end_timing(rr, capacity):
+        buf, nfr = (C.c_float * capacity)(), C.c_int()
+        rr._check(rr._lib.rpt_timing_end_frames(rr._h, buf, capacity, C.byref(nfr)), "rpt_timing_end_frames")
+        return list(buf[:nfr.value])
+
     def timed(steps):
-        """K steps bracketed by barrier + device sync; returns (wall s, mean launch ms, sum of launch ms) of this rank."""
+        """K steps bracketed by barrier + device sync; returns (wall s, per-launch durations in ms) of this rank."""
         for rr in renderers:
             rr._check(rr._lib.rpt_timing_begin(rr._h, steps), "rpt_timing_begin")
         barrier()
@@ -227,33 +330,33 @@ def main():
         wall = time.perf_counter() - t0
         if rank == 0 and os.environ.get("RPT_BENCH_VERBOSE") == "1":
             print(f"[bench] host submission {submit / steps * 1e3:.4f} ms/step, wall {wall / steps * 1e3:.4f} ms/step", file=sys.stderr)
-        total, count = 0.0, 0
+        launches = []
         for rr in renderers:
-            tot, nfr = C.c_float(), C.c_int()
-            rr._check(rr._lib.rpt_timing_end(rr._h, C.byref(tot), C.byref(nfr)), "rpt_timing_end")
-            total += tot.value
-            count += nfr.value
-        return wall, total / max(count, 1), total
+            launches += end_timing(rr, steps)
+        return wall, launches
 
     for _ in range(max(args.warmup, 0)):
         step()
-    elapsed, kernel_ms, kernel_sum_ms = timed(args.steps)     # launch duration: HIP events on the launch's own stream
+    elapsed, launches = timed(args.steps)     # launch durations: HIP events on each launch's own stream
+    kernel_ms = sum(launches) / max(len(launches), 1)
+    kernel_sum_ms = sum(launches)
 
     # the same frames one at a time (submit, wait, submit ...: what the reference's blocking runKernel() does) — the
     # frame LATENCY, and the launch duration without other launches sharing the device
     blocking_ms = blocking_kernel_ms = None
+    blocking_frames, blocking_launches = [], []
     if n == 1 and not force_dist:
-        nb = max(1, min(args.steps, 30))
+        nb = max(1, min(args.steps, 50))
         barrier()
         r._check(r._lib.rpt_timing_begin(r._h, nb), "rpt_timing_begin")
-        t0 = time.perf_counter()
         for _ in range(nb):
+            t0 = time.perf_counter()
             frame.slots[0].r.set_objects(scene)
             frame.slots[0].r.render()
-        blocking_ms = (time.perf_counter() - t0) / nb * 1e3
-        tot, nfr = C.c_float(), C.c_int()
-        r._check(r._lib.rpt_timing_end(r._h, C.byref(tot), C.byref(nfr)), "rpt_timing_end")
-        blocking_kernel_ms = tot.value / max(nfr.value, 1)
+            blocking_frames.append((time.perf_counter() - t0) * 1e3)
+        blocking_ms = sum(blocking_frames) / nb
+        blocking_launches = end_timing(r, nb)
+        blocking_kernel_ms = sum(blocking_launches) / max(len(blocking_launches), 1)
         frame.last = frame.slots[0]
         frame.slots[0].frames += nb
 
@@ -279,6 +382,7 @@ def main():
         # the region = average number of launches running at once.  A launch's share of the device is then
         # duration / overlap, and achieved = bytes per launch / that (= bytes of all launches / wall time).
         overlap = max(1.0, kernel_sum_ms / (elapsed * 1e3)) if frame.depth > 1 else 1.0
+        kernel_name = (DEFAULT_KERNEL if args.variant == 0 else f"kernel variant {args.variant} (rpt_set_variant, include/rpt.h)")
         achieved = alg / (kernel_ms / overlap * 1e-3) / 1e9
         out = {
             "metric": "Mrays/s (primary rays) on Scenes/bunny.txt at 3840x2160" if (args.workload, W, H) == ("bunny", 3840, 2160)
@@ -296,35 +400,45 @@ def main():
                                     f"weighted: per {root_run + n - 1} tiles rank 0 renders {root_run} in place, ranks 1..{n - 1} one each into 3 B/px planes"),
                        "split_calibration": split_info,
                        "variant": args.variant},
+            # --- the two regimes, side by side, so that they cannot be confused -------------------------------------
+            # value / ms_per_step above: THROUGHPUT with `frames_in_flight` frames overlapping on the device (every frame
+            # refreshed and rendered completely); ms_per_step is the interval between finished frames, not a latency.
+            # blocking: the same frames submitted and waited for one by one, like the reference's runKernel(): LATENCY.
+            "regime": f"{frame.depth} frames in flight" if frame.depth > 1 else "one frame at a time",
+            "ms_per_frame_blocking": None if blocking_ms is None else round(blocking_ms, 4),
+            "value_blocking": None if blocking_ms is None else round(W * H / blocking_ms / 1e3, 2),
+            "frame_ms_blocking": spread(blocking_frames),          # host-timed submit+wait of each frame
+            "launch_ms_in_flight": spread(launches),               # HIP events around each launch, launches overlapping
+            "launch_ms_blocking": spread(blocking_launches),       # the same, one launch at a time
             "kernel_ms": round(kernel_ms, 4),
             "one_frame_at_a_time": None if blocking_ms is None else {
                 "ms_per_frame": round(blocking_ms, 4), "value": round(W * H / blocking_ms / 1e3, 2), "kernel_ms": round(blocking_kernel_ms, 4),
                 "note": "submit, wait, submit ... like the reference's blocking runKernel(): the frame latency"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "rpt_render_kernel_v1_masked_w5 (+ rpt_tile_bin_kernel prepass)" if args.variant == 0
-                                   else f"kernel variant {args.variant} (rpt_set_variant, include/rpt.h)", "algorithmic_bytes_per_launch": alg,
+                         "kernel": kernel_name, "algorithmic_bytes_per_launch": alg,
                          "launch_ms": round(kernel_ms, 4), "launches_overlapped": round(overlap, 3),
+                         "regime": f"{frame.depth} frames in flight: achieved = bytes of all launches / wall time of the region",
                          "definition": "achieved = algorithmic_bytes_per_launch / (launch_ms / launches_overlapped): launch_ms is the mean "
                                        "HIP-event duration of one launch on its own stream (what rocprofv3 reports per dispatch), "
                                        "launches_overlapped the mean number of launches sharing the device in the timed region",
                          "note": "16 B/pixel written + 320 B/object read per launch (SURVEY.md §8d); the path is "
                                  "latency/VALU-bound by construction, HBM fraction reported because it is the contract"},
         }
-        # HBM traffic of the same launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
-        # WRITE_SIZE, MI355X_MICROARCH.md §HBM); PMC cannot be collected from inside this process
-        prof = os.path.join(ROOT, "profiles", "r01_final2_bunny4k_pmc_summary.json")
-        if (args.workload, W, H, n, args.variant) == ("bunny", 3840, 2160, 1, 0) and not force_dist and os.path.exists(prof):
-            try:
-                d = json.load(open(prof))["derived"]
-                out["roofline"]["traffic"] = int(sum(v for k, v in d.items() if k.startswith("hbm_")))
-                out["roofline"]["traffic_source"] = "profiles/r01_final2_bunny4k_pmc_summary.json (rocprofv3 --pmc, same command; tools/profile.sh + tools/pmc_summary.py)"
-            except Exception:
-                pass
+        # HBM traffic of the same launch: rocprofv3 PMC passes of this command, quoted only when taken on THIS build
+        if n == 1 and not force_dist and args.variant == 0:
+            traffic, source = measured_traffic(args.workload, W, H)
+            out["roofline"]["traffic"] = traffic
+            out["roofline"]["traffic_source"] = (f"{source} (rocprofv3 --pmc of this command on this build of librpt_hip.so: recorded hash matches)"
+                                                 if source else "no committed PMC summary was taken on this build of librpt_hip.so")
         if blocking_kernel_ms:
             a1 = alg / (blocking_kernel_ms * 1e-3) / 1e9
-            out["roofline"]["single_launch"] = {"launch_ms": round(blocking_kernel_ms, 4), "achieved": round(a1, 2),
-                                                "frac": round(a1 / HBM_PEAK_GBS, 5), "note": "one launch at a time, nothing overlapped"}
+            out["roofline"]["blocking"] = {"launch_ms": round(blocking_kernel_ms, 4), "achieved": round(a1, 2),
+                                           "frac": round(a1 / HBM_PEAK_GBS, 5), "note": "one launch at a time, nothing overlapped: "
+                                           "algorithmic bytes / the launch's own HIP-event duration"}
+            out["roofline"]["frac_blocking"] = round(a1 / HBM_PEAK_GBS, 5)
+        if n > 1 or force_dist:
+            out["comm"] = {"backend": td.get_backend(), "world_size": n, "ranks_in_group": td.get_world_size()}
         if not args.no_cpu_baseline and n == 1:
             out["cpu_baseline"] = cpu_baseline(scene, W, H)
             # second column of SURVEY.md §8(d): primary + shadow rays, the shadow rays counted by the oracle

@@ -90,24 +90,26 @@ int rpt_set_rows(rpt_ctx *ctx, int first_tile, int tile_step, int colour_plane);
  * its plane — the root takes the larger share because its pixels need no exchange. */
 int rpt_set_tile_pattern(rpt_ctx *ctx, int first_tile, int tile_step, int run, int colour_plane);
 
-/* Launch on this HIP stream (hipStream_t as void*; NULL = the context's own stream). */
+/* Launch on this HIP stream (hipStream_t as void*; NULL = the context's own stream).  The stream stays the caller's: it
+ * must outlive every launch made on it (rpt_sync, or the caller's own synchronisation, before it is destroyed).  Switching
+ * away from an external stream waits for the context's last launch through an event, not through the stream handle, and
+ * rpt_destroy waits for the device — so a handle destroyed after its work has finished is never touched again. */
 int rpt_set_stream(rpt_ctx *ctx, void *hip_stream);
 
 /* Test hook: also write the tonemapped float RGB before 8-bit packing (3 floats/pixel, row-major,
  * width*height*12 B) to this device pointer; NULL disables. 1 = library-owned buffer. */
 int rpt_set_debug_rgb(rpt_ctx *ctx, void *device_ptr_or_null_or_1);
 
-/* Kernel variant: 0 = default (fastest validated), others select alternative implementations of
- * the same path for A/B measurement; all produce identical results.
- *   0  default: 26, or 1 when the octree's children are not stored consecutively
- *   1  reads the reference's Octree/triangle layouts only (any valid octree)
- *   2, 3, 4   derived layouts, uncapped / 4 / 5 waves per SIMD, every object tested for every pixel
- *   15, 16    + walk with neighbour prefetch and branch-free triangle pairs (uncapped / 4 waves)
- *   25, 26, 27  per-tile object masks from the prepass, 4 / 5 / 6 waves per SIMD
- *   28  masks + triangle-record prefetch;  31  masks + the pipelined walk
+/* Kernel variant: 0 = default (fastest validated); the others select alternative implementations of the same path for
+ * A/B measurement.  All produce identical results.
+ *   0   default: 41, or 1 when the octree's children are not stored consecutively
+ *   1   reads the reference's Octree/triangle layouts only (any valid octree)
+ *   3   derived layouts, every object tested for every pixel (no culling), 4 waves per SIMD
+ *   26  per-tile object masks from a prepass kernel (round 1's default), 5 waves per SIMD
  *   40, 41, 42  no prepass: every wavefront builds its own object mask from per-object image-plane rectangles
  *               (computed on the host in rpt_set_objects) with one lane-parallel test + __ballot; 4 / 5 / 6 waves per SIMD
- *   7, 8, 11  diagnostic builds (loop counters, primary rays only, per-wave timeline): not product paths */
+ * The diagnostic kernels (7 loop counters, 8 primary rays only, 11 per-wave timeline) are not in the product library:
+ * `make -C relativitypathtracer_amd/csrc diag` builds librpt_hip_diag.so with them (tools/divergence.py, tools/timeline.py). */
 int rpt_set_variant(rpt_ctx *ctx, int variant);
 
 /* The per-object cull record of the default kernel, exposed for tests (host code, needs no device): the rectangle
@@ -142,6 +144,8 @@ int rpt_timed_frames(rpt_ctx *ctx, int frames, float *avg_ms);
  * rpt_timing_end waits for them and returns the summed kernel time and the frame count. */
 int rpt_timing_begin(rpt_ctx *ctx, int max_frames);
 int rpt_timing_end(rpt_ctx *ctx, float *total_ms, int *frames);
+/* The same, returning every frame's launch duration (up to `capacity`) instead of their sum. */
+int rpt_timing_end_frames(rpt_ctx *ctx, float *per_frame_ms, int capacity, int *frames);
 
 /* Root side of the multi-GPU exchange: expand `n_ranks` gathered colour planes (rank r's plane at
  * planes + r*plane_stride_bytes) into the 16 B/pixel framebuffer `out16` (x, y, packed colour). */
@@ -166,14 +170,14 @@ int rpt_scatter_colour_plane3_on(rpt_ctx *ctx, void *hip_stream, const void *pla
 int rpt_scatter_helper_planes3_on(rpt_ctx *ctx, void *hip_stream, const void *planes3, void *out16, int width, int height,
                                   int n_ranks, int root_run, size_t plane_stride_bytes);
 
-/* Diagnostic variant 7 only: loop-iteration counters of the octree walk of the last frame —
+/* Diagnostic variant 7 only (librpt_hip_diag.so): loop-iteration counters of the octree walk of the last frame —
  * [0..2] leaf steps / triangle tests / descent steps summed over lanes, [3..5] the same counted
  * once per executing wavefront (lane sum / (64 * wave count) = SIMD utilisation of that loop); [6] longest walk,
  * [7] walks > 32 steps, [8] sum over leaf steps of distinct nodes among the active lanes, [9] sum of active lanes,
  * [10..15] histogram of distinct nodes per step (1, 2, 3-4, 5-8, 9-16, >16). */
 int rpt_read_counters(rpt_ctx *ctx, unsigned long long out[16]);
 
-/* Diagnostic variant 11 only: ten words per wavefront of the last frame — {start, end} stamps (100 MHz
+/* Diagnostic variant 11 only (librpt_hip_diag.so): ten words per wavefront of the last frame — {start, end} stamps (100 MHz
  * s_memrealtime) and the cycle / iteration accounting of the walk's loops (tools/timeline.py);
  * wave w = (blockIdx.y*gridDim.x + blockIdx.x)*4 + wave-in-block. */
 int rpt_read_wave_times(rpt_ctx *ctx, unsigned long long *out, size_t max_words, size_t *words);
@@ -190,7 +194,8 @@ int rpt_build_octree(rpt_ctx *ctx, const rpt_float3 *vertices, size_t vertex_cou
 void rpt_free_host(void *p);
 
 /* Known-answer probes of individual device functions (tests): which = 0 intersect_triangle
- * (in 15 floats -> out 4), 1 intersect_AABB (12 -> 5), 2 createCamRay (4 -> 3), 3 hable (3 -> 3). */
+ * (in 15 floats -> out 4), 1 intersect_AABB (12 -> 5), 2 createCamRay (4 -> 3), 3 hable (3 -> 3), 4 asin / atan2 of the
+ * textured-sphere (u,v) (3 -> 2), 5 the walk's pure steps: exit face of a leaf and child selection, general and fast (6 -> 12). */
 int rpt_probe(rpt_ctx *ctx, int which, const void *host_in, void *host_out, int n);
 
 #ifdef __cplusplus

@@ -150,6 +150,7 @@ HIP_SYMBOLS = {
     "rpt_set_plane_output": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rpt_timing_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "rpt_timing_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "rpt_timing_end_frames": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),
     "rpt_read_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rpt_read_wave_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rpt_build_octree": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
@@ -161,7 +162,8 @@ HIP_SYMBOLS = {
 
 
 def hip_lib_path() -> str:
-    return _path("librpt_hip.so")
+    """librpt_hip.so; RPT_HIP_LIB names another build of it (the diagnostics build librpt_hip_diag.so, for the tools)."""
+    return os.environ.get("RPT_HIP_LIB") or _path("librpt_hip.so")
 
 
 def _share_torch_hip_runtime():

@@ -391,34 +391,14 @@ int launch(rpt_ctx *ctx) {
     const int tiles = local_tile_count(ctx);
     if (tiles == 0) return RPT_OK;
     const dim3 grid((ctx->width + 31) / 32, tiles);
-    // variant 0 = default: the derived-layout per-pixel kernel in natural dispatch order with the per-tile object
-    // masks of the prepass, 5 waves per SIMD (26) when the octree allows the derived layout, else the general kernel (1)
-    int v = ctx->variant == 0 ? 26 : ctx->variant;
+    // variant 0 = default: the derived-layout per-pixel kernel whose wavefronts build their own object masks from the
+    // per-object screen rectangles (41), 5 waves per SIMD, when the octree allows the derived layout; else the general kernel (1)
+    int v = ctx->variant == 0 ? 41 : ctx->variant;
     if (!ctx->geo->compact_ok) v = 1;
     switch (v) {
     case 1: hipLaunchKernelGGL(rptd::rpt_render_kernel_v0, grid, dim3(256), 0, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1, grid, dim3(256), 0, ctx->stream, a); break;
     case 3: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_w4, grid, dim3(256), 0, ctx->stream, a); break;
-    case 4: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_w5, grid, dim3(256), 0, ctx->stream, a); break;
-    case 7:
-        if (int rc = reserve(ctx, ctx->counters, 16 * sizeof(unsigned long long))) return rc;
-        RPT_HIP(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 16 * sizeof(unsigned long long), ctx->stream));
-        a.counters = (unsigned long long *)ctx->counters.ptr;
-        hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_diag, grid, dim3(256), 0, ctx->stream, a);
-        break;
-    case 11:
-        if (int rc = reserve(ctx, ctx->wave_times, (size_t)grid.x * grid.y * 4 * 10 * sizeof(unsigned long long))) return rc;
-        RPT_HIP(ctx, hipMemsetAsync(ctx->wave_times.ptr, 0, ctx->wave_times.bytes, ctx->stream));
-        a.wave_times = (unsigned long long *)ctx->wave_times.ptr;
-        hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_timeline, grid, dim3(256), 0, ctx->stream, a);
-        break;
-    case 15: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_pipe, grid, dim3(256), 0, ctx->stream, a); break;
-    case 16: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_pipe_w4, grid, dim3(256), 0, ctx->stream, a); break;
-    case 25:
-    case 26:
-    case 27:
-    case 28:
-    case 31: {   // natural order, per-tile object masks from the prepass
+    case 26: {   // round 1's default: per-tile object masks from a prepass kernel
         const int tiles_x = ((ctx->width + 31) / 32) * 4;          // tiles per row as the 32-pixel-wide blocks see them
         const int n_tiles = tiles_x * tiles;
         if (int rc = reserve(ctx, ctx->tile_masks, (size_t)n_tiles * 8)) return rc;
@@ -426,17 +406,27 @@ int launch(rpt_ctx *ctx) {
         a.n_tiles = n_tiles;
         a.tile_masks = (unsigned long long *)ctx->tile_masks.ptr;
         hipLaunchKernelGGL(rptd::rpt_tile_bin_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, ctx->stream, a);
-        if (v == 25) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked, grid, dim3(256), 0, ctx->stream, a);
-        else if (v == 26) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_w5, grid, dim3(256), 0, ctx->stream, a);
-        else if (v == 27) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_w6, grid, dim3(256), 0, ctx->stream, a);
-        else if (v == 31) hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_pipe_w4, grid, dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_pf, grid, dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_w5, grid, dim3(256), 0, ctx->stream, a);
         break;
     }
-    case 8: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only, grid, dim3(256), 0, ctx->stream, a); break;
     case 40: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w4, grid, dim3(256), 0, ctx->stream, a); break;
     case 41: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w5, grid, dim3(256), 0, ctx->stream, a); break;
     case 42: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w6, grid, dim3(256), 0, ctx->stream, a); break;
+#ifdef RPT_DIAGNOSTICS
+    case 7:
+        if (int rc = reserve(ctx, ctx->counters, 16 * sizeof(unsigned long long))) return rc;
+        RPT_HIP(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 16 * sizeof(unsigned long long), ctx->stream));
+        a.counters = (unsigned long long *)ctx->counters.ptr;
+        hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_diag, grid, dim3(256), 0, ctx->stream, a);
+        break;
+    case 8: hipLaunchKernelGGL(rptd::rpt_render_kernel_primary_only, grid, dim3(256), 0, ctx->stream, a); break;
+    case 11:
+        if (int rc = reserve(ctx, ctx->wave_times, (size_t)grid.x * grid.y * 4 * 10 * sizeof(unsigned long long))) return rc;
+        RPT_HIP(ctx, hipMemsetAsync(ctx->wave_times.ptr, 0, ctx->wave_times.bytes, ctx->stream));
+        a.wave_times = (unsigned long long *)ctx->wave_times.ptr;
+        hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_timeline, grid, dim3(256), 0, ctx->stream, a);
+        break;
+#endif
     default: return fail(ctx, RPT_ERR_ARG, "unknown kernel variant");
     }
     RPT_HIP(ctx, hipGetLastError());
@@ -447,7 +437,11 @@ int launch(rpt_ctx *ctx) {
 
 extern "C" {
 
-const char *rpt_version(void) { return "rpt-hip 0.1 (gfx950)"; }
+#ifdef RPT_DIAGNOSTICS
+const char *rpt_version(void) { return "rpt-hip 0.2 (gfx950, diagnostics build)"; }
+#else
+const char *rpt_version(void) { return "rpt-hip 0.2 (gfx950)"; }
+#endif
 
 int rpt_create(rpt_ctx **out, int device_ordinal) {
     if (!out) return RPT_ERR_ARG;
@@ -474,7 +468,9 @@ int rpt_create(rpt_ctx **out, int device_ordinal) {
 void rpt_destroy(rpt_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    // work of this context may still be running on an external stream (rpt_set_stream) whose handle the caller may already
+    // have destroyed: wait for the device rather than for a handle that may be dead, then free
+    (void)hipDeviceSynchronize();
     ctx->geo.reset();
     for (DeviceBuffer *b : {&ctx->objects, &ctx->dobjs, &ctx->counters, &ctx->wave_times, &ctx->tile_masks, &ctx->owned_out, &ctx->owned_plane, &ctx->owned_rgb})
         release(*b);
@@ -626,7 +622,10 @@ int rpt_set_tile_pattern(rpt_ctx *ctx, int first_tile, int tile_step, int run, i
 int rpt_set_stream(rpt_ctx *ctx, void *hip_stream) {
     if (!ctx) return RPT_ERR_ARG;
     RPT_HIP(ctx, hipSetDevice(ctx->device));
-    RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // drain what this context has enqueued on the stream it is leaving.  If that is an external stream the caller has
+    // destroyed in the meantime, the handle is dead: the context's last launch is then waited for through its event.
+    if (ctx->stream == ctx->own_stream) RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    else if (ctx->frame_rendered) RPT_HIP(ctx, hipEventSynchronize(ctx->ev_end));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return RPT_OK;
 }
@@ -646,7 +645,14 @@ int rpt_object_screen_rect(const void *object, int interval, const float *root_b
 }
 
 int rpt_set_variant(rpt_ctx *ctx, int variant) {
-    if (!ctx || variant < 0 || variant > 63) return RPT_ERR_ARG;
+    if (!ctx) return RPT_ERR_ARG;
+    switch (variant) {
+    case 0: case 1: case 3: case 26: case 40: case 41: case 42: break;
+#ifdef RPT_DIAGNOSTICS
+    case 7: case 8: case 11: break;
+#endif
+    default: return fail(ctx, RPT_ERR_ARG, "rpt_set_variant: unknown variant (diagnostic variants 7, 8, 11 exist in librpt_hip_diag.so only)");
+    }
     ctx->variant = variant;
     return RPT_OK;
 }
@@ -694,6 +700,20 @@ int rpt_timing_end(rpt_ctx *ctx, float *total_ms, int *frames) {
     }
     *total_ms = sum;
     *frames = ctx->timing_frames;
+    ctx->timing_frames = -1;
+    return RPT_OK;
+}
+
+int rpt_timing_end_frames(rpt_ctx *ctx, float *per_frame_ms, int capacity, int *frames) {
+    if (!ctx || !per_frame_ms || capacity < 0 || !frames) return RPT_ERR_ARG;
+    if (ctx->timing_frames < 0) return fail(ctx, RPT_ERR_STATE, "rpt_timing_end_frames without rpt_timing_begin");
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    const int n = ctx->timing_frames < capacity ? ctx->timing_frames : capacity;
+    for (int i = 0; i < n; i++) {
+        RPT_HIP(ctx, hipEventSynchronize(ctx->timing_events[2 * i + 1]));
+        RPT_HIP(ctx, hipEventElapsedTime(&per_frame_ms[i], ctx->timing_events[2 * i], ctx->timing_events[2 * i + 1]));
+    }
+    *frames = n;
     ctx->timing_frames = -1;
     return RPT_OK;
 }

@@ -402,28 +402,6 @@ RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &
         }
         const int trisIndex = node.tri_begin(a);
         const int trisEnd = trisIndex + node.tri_count(a);
-        if (V == 11) {
-            // the leaf's records are consecutive: request record k+1 before record k is tested, alternating between two
-            // register sets so that no copy (and with it no wait) sits between the request and the test it overlaps
-            int k = trisIndex;
-            if (k < trisEnd) {
-                DTriRec ra = load_dtri(a, k), rb;
-                while (true) {
-                    rb = load_dtri(a, k + 1 < trisEnd ? k + 1 : k);
-                    float dist;
-                    f2 triUV;
-                    if (intersect_triangle_edges(ra.A, ra.v0v1, ra.v0v2, newRay, dist, triUV) && 0 <= dist && dist < hit.dist) {
-                        hitTri = ra.id; hit.dist = dist; hit.uv = triUV; didHit = true;
-                    }
-                    if (++k >= trisEnd) break;
-                    ra = load_dtri(a, k + 1 < trisEnd ? k + 1 : k);
-                    if (intersect_triangle_edges(rb.A, rb.v0v1, rb.v0v2, newRay, dist, triUV) && 0 <= dist && dist < hit.dist) {
-                        hitTri = rb.id; hit.dist = dist; hit.uv = triUV; didHit = true;
-                    }
-                    if (++k >= trisEnd) break;
-                }
-            }
-        } else
         for (int i = trisIndex; i < trisEnd; i++) {
             f3 A, v0v1, v0v2;
             int tri;
@@ -455,117 +433,6 @@ RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &
     if (V == 2) {   // diagnostic: longest single walk (leaf steps) and a coarse histogram of walk lengths
         atomicMax(&a.counters[6], (unsigned long long)steps);
         if (steps > 32) atomicAdd(&a.counters[7], 1ull);
-    }
-    if (!didHit) return false;
-
-    const float u = hit.uv.x, v = hit.uv.y;
-    const float w = 1.0f - u - v;
-    const f3 normA = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 0]]);
-    const f3 normB = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 1]]);
-    const f3 normC = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 2]]);
-    hit.normal = normalize(applyTranspose(obj.InvM, normA * w + normB * u + normC * v));
-    const rpt_float2 uvA = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 0]];
-    const rpt_float2 uvB = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 1]];
-    const rpt_float2 uvC = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 2]];
-    hit.uv.x = w * uvA.x + u * uvB.x + v * uvC.x;
-    hit.uv.y = w * uvA.y + u * uvB.y + v * uvC.y;
-    const f3 objPoint = newRay.origin + newRay.dir * hit.dist;
-    const f3 worldPoint = transformPoint(obj.M, objPoint);
-    hit.dist = length(worldPoint - world_origin) / world_dirlen;
-    return true;
-}
-
-// The same walk with its memory latency taken off the dependent chain (derived layouts only):
-//   * the exit face and the neighbour index of a leaf depend only on (uv, bounds), not on its triangles,
-//     so they are computed FIRST and the neighbour's 64-B record is requested before the triangle loop;
-//   * triangle records of a leaf are contiguous: record k+1 is requested before record k is tested.
-// Per leaf step the only loads left on the critical path are the descent levels.  Arithmetic and the
-// order of hit updates are those of octree_core (the break test still sees the leaf's final hit.dist).
-// Two triangles of a leaf at once, without branches: both Moller-Trumbore chains are independent and
-// interleave (ILP for a wave that is alone on its SIMD), and the six record loads are one round trip.
-// Accept/reject and the update order are those of the sequential loop (first `a`, then `b`).
-RPT_DEV void tri_update(const DTriRec &t, const Ray &ray, bool valid, Hit &hit, int &hitTri, bool &didHit) {
-    const f3 pvec = cross(ray.dir, t.v0v2);
-    const float det = dot(t.v0v1, pvec);
-    const float invDet = 1 / det;
-    const f3 tvec = ray.origin - t.A;
-    const float u = dot(tvec, pvec) * invDet;
-    const f3 qvec = cross(tvec, t.v0v1);
-    const float v = dot(ray.dir, qvec) * invDet;
-    const float dist = dot(t.v0v2, qvec) * invDet;
-    const bool reject = (det < RPT_EPSILON && -RPT_EPSILON < det) || (u < 0 || u > 1) || (v < 0 || u + v > 1);
-    const bool take = valid && !reject && (0 <= dist && dist < hit.dist);
-    hitTri = take ? t.id : hitTri;
-    hit.dist = take ? dist : hit.dist;
-    hit.uv.x = take ? u : hit.uv.x;
-    hit.uv.y = take ? v : hit.uv.y;
-    didHit = didHit || take;
-}
-
-RPT_DEV bool octree_core_pipelined(const KernelArgs &a, const rpt_object &obj, const Ray &newRay, f3 world_origin,
-                                   float world_dirlen, Hit &hit) {
-    NodeRef<1> node;
-    int currOctreeIndex = obj.meshIndex;
-    node.load(a, currOctreeIndex);
-    f2 d;
-    int closeSide, farSide;
-    f3 nmin = node.bmin(a), nmax = node.bmax(a);
-    if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
-    f3 uv = newRay.origin + newRay.dir * d.x;
-
-    if (d.x < 0) {
-        uv = (newRay.origin - nmin) / (nmax - nmin);
-        while (!node.is_leaf(a)) {
-            const int childIndex = octree_child_step_fast(uv);
-            currOctreeIndex = node.child(a, childIndex);
-            node.load(a, currOctreeIndex);
-        }
-        nmin = node.bmin(a);
-        nmax = node.bmax(a);
-        if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
-        uv = newRay.origin + newRay.dir * d.x;
-    }
-
-    const ExitPlan plan = makeExitPlan(normalize(newRay.dir / (nmax - nmin)));
-    bool didHit = false;
-    int hitTri = 0;
-    int steps = 0;
-    // invariant at the top of the loop: `node` holds the record of currOctreeIndex (!= -1)
-    while (true) {
-        if (++steps > RPT_MAX_LEAF_STEPS) break;
-        nmin = node.bmin(a);
-        nmax = node.bmax(a);
-        uv = (uv - nmin) / (nmax - nmin);
-        bool descended = false;
-        while (!node.is_leaf(a)) {
-            const int childIndex = octree_child_step_fast(uv);
-            currOctreeIndex = node.child(a, childIndex);
-            node.load(a, currOctreeIndex);
-            descended = true;
-        }
-        if (descended) {
-            nmin = node.bmin(a);
-            nmax = node.bmax(a);
-        }
-        int k = node.tri_begin(a);
-        const int kend = k + node.tri_count(a);
-        const f3 extents = nmax - nmin;
-        farSide = getOppositeBoxSide(plan, uv);
-        uv = nmin + uv * extents;
-        const int nextIndex = node.neighbor(a, farSide);
-        NodeRef<1> nextNode;
-        nextNode.load(a, nextIndex < 0 ? currOctreeIndex : nextIndex);   // always a valid record: no branch around the loads
-        while (k < kend) {
-            const DTriRec ta = load_dtri(a, k);
-            const DTriRec tb = load_dtri(a, k + 1 < kend ? k + 1 : k);
-            tri_update(ta, newRay, true, hit, hitTri, didHit);
-            tri_update(tb, newRay, k + 1 < kend, hit, hitTri, didHit);
-            k += 2;
-        }
-        currOctreeIndex = nextIndex;
-        if (length(uv - newRay.origin) > hit.dist) break;
-        if (currOctreeIndex == -1) break;
-        node = nextNode;
     }
     if (!didHit) return false;
 
@@ -658,7 +525,6 @@ RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, H
         Ray newRay;
         newRay.origin = origin;
         newRay.dir = dir;
-        if (V == 6 || V == 12) return octree_core_pipelined(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
         return octree_core<V>(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
     }
     default:
@@ -688,7 +554,6 @@ RPT_DEV bool intersect_object_primary(const KernelArgs &a, int i, f4 rayDir, Hit
         newRay.origin = origin;
         newRay.dir = dir;
         const f3 cam3 = mk3(obj.stationaryCam.y, obj.stationaryCam.z, obj.stationaryCam.w);
-        if (V == 6 || V == 12) return octree_core_pipelined(a, obj, newRay, cam3, length(d3), hit);
         return octree_core<V>(a, obj, newRay, cam3, length(d3), hit);
     }
     default:
@@ -874,8 +739,9 @@ RPT_DEV unsigned long long wave_object_mask(const KernelArgs &a, int tile_x0, in
 // One thread per pixel, wave = 8x8 tile, workgroup = 32x8 strip.
 //   V = 0: reads the reference layouts only (general fallback, any valid octree)
 //   V = 1: derived DNode/DTri/DObj layouts
-//   V = 2, 3, 4: diagnostic builds (loop counters, primary rays only, per-wave timeline); V = 6: pipelined walk
-//   V = 10: per-tile object masks from the prepass (the default); 11: + triangle-record prefetch; 12: + pipelined walk
+//   V = 2, 3, 4: diagnostic builds (loop counters, primary rays only, per-wave timeline; -DRPT_DIAGNOSTICS only)
+//   V = 10: per-tile object masks from the prepass kernel (round 1's default, kept for A/B)
+//   V = 20: the wave's object mask from per-object image-plane rectangles + __ballot (the default)
 template <int V>
 RPT_DEV void render_pixel_body(const KernelArgs &a) {
     const int lane = threadIdx.x & 63;
@@ -901,11 +767,11 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
     f3 color;
     f3 mapped = mk3(a.bg_mapped[0], a.bg_mapped[1], a.bg_mapped[2]);
     uint32_t packed = a.bg_packed;
-    if (V == 10 || V == 11 || V == 12) {   // per-tile object mask of the prepass
+    if (V == 10) {   // per-tile object mask of the prepass
         const int tile = __builtin_amdgcn_readfirstlane(tile_row * a.tiles_x + (int)blockIdx.x * 4 + wave);
         object_mask = a.tile_masks[tile];
     }
-    const bool masked = V == 10 || V == 11 || V == 12 || V >= 20;
+    const bool masked = V == 10 || V >= 20;
     if (!masked || object_mask != 0 || a.object_count > 64) {
         const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);
         if (trace<V>(a, camdir, object_mask, color)) packed = tonemap_pack(a, color, mapped);
@@ -939,24 +805,19 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
     }
 }
 
-__global__ __launch_bounds__(256) void rpt_render_kernel_v0(const KernelArgs a) { render_pixel_body<0>(a); }
-__global__ __launch_bounds__(256) void rpt_render_kernel_v1(const KernelArgs a) { render_pixel_body<1>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_w4(const KernelArgs a) { render_pixel_body<1>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_v1_w5(const KernelArgs a) { render_pixel_body<1>(a); }
+// Product kernels (rpt_set_variant): the default, the general fallback and the A/B forms kept for measurement.
+__global__ __launch_bounds__(256) void rpt_render_kernel_v0(const KernelArgs a) { render_pixel_body<0>(a); }                                                            // 1
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_w4(const KernelArgs a) { render_pixel_body<1>(a); }           // 3
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_v1_masked_w5(const KernelArgs a) { render_pixel_body<10>(a); }   // 26
+// V = 20: the wave's object mask from the per-object screen rectangles by lane-parallel test + __ballot (no prepass)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_ballot_w4(const KernelArgs a) { render_pixel_body<20>(a); }       // 40
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_w5(const KernelArgs a) { render_pixel_body<20>(a); }       // 41 = default
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_ballot_w6(const KernelArgs a) { render_pixel_body<20>(a); }       // 42
+#ifdef RPT_DIAGNOSTICS   /* librpt_hip_diag.so only (make diag): loop counters, primary rays only, per-wave timeline */
 __global__ __launch_bounds__(256) void rpt_render_kernel_v1_diag(const KernelArgs a) { render_pixel_body<2>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_timeline(const KernelArgs a) { render_pixel_body<4>(a); }
-__global__ __launch_bounds__(256) void rpt_render_kernel_v1_pipe(const KernelArgs a) { render_pixel_body<6>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_pipe_w4(const KernelArgs a) { render_pixel_body<6>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_masked(const KernelArgs a) { render_pixel_body<10>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_masked_pf(const KernelArgs a) { render_pixel_body<11>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_v1_masked_w5(const KernelArgs a) { render_pixel_body<10>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_v1_masked_w6(const KernelArgs a) { render_pixel_body<10>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_masked_pipe_w4(const KernelArgs a) { render_pixel_body<12>(a); }
 __global__ __launch_bounds__(256) void rpt_render_kernel_primary_only(const KernelArgs a) { render_pixel_body<3>(a); }
-// V = 20: the wave's object mask from the per-object screen rectangles by lane-parallel test + __ballot (no prepass)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_ballot_w4(const KernelArgs a) { render_pixel_body<20>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_w5(const KernelArgs a) { render_pixel_body<20>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_ballot_w6(const KernelArgs a) { render_pixel_body<20>(a); }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Tile-mask prepass (one thread per 8x8 tile).  For every object it asks whether ANY primary ray

@@ -1,0 +1,64 @@
+"""bench.py's command line: `python bench.py --gpus N` works BARE (it starts its own ranks through torch.distributed.run
+before touching a device and relays rank 0's line), the N > 1 plumbing — rendezvous on 127.0.0.1, barriers, max over
+ranks, one JSON line — is exercised without a device by --dry-run, and without a GPU the real run fails loudly."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config"}
+
+
+def run_bench(*args, env=None, timeout=600):
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, cwd=ROOT,
+                          env={**clean, **(env or {})}, timeout=timeout)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_bare_gpus_n_launches_its_own_ranks(n):
+    p = run_bench("--gpus", str(n), "--steps", "4", "--warmup", "1", "--dry-run")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout                      # rank 0 alone prints, once
+    out = json.loads(lines[0])
+    assert CONTRACT_KEYS <= set(out)
+    assert out["n_gpus"] == n and out["steps"] == 4 and out["warmup"] == 1 and out["dry_run"] is True
+    assert out["comm"]["ranks_in_group"] == n and out["comm"]["world_size"] == n
+    assert out["config"]["workload"].startswith("Scenes/bunny.txt 3840x2160") and "model" not in out["config"]
+
+
+def test_dry_run_accepts_config_5():
+    p = run_bench("--gpus", "2", "--dry-run", "--width", "7680", "--height", "4320")
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "7680x4320" in out["config"]["workload"]
+
+
+def test_real_run_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    for n in ("1", "2"):
+        p = run_bench("--gpus", n, "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+        assert p.returncode != 0
+        assert "needs a GPU" in (p.stderr + p.stdout)
+        assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]      # no line, no silent CPU fallback
+
+
+@pytest.mark.gpu
+def test_bare_single_gpu_line():
+    """The driver's own N = 1 command form on the GPU box: one line, the contract's keys, roofline + regimes."""
+    p = run_bench("--gpus", "1", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--workload", "shadows", "--width", "1280", "--height", "720", "--check")
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert CONTRACT_KEYS <= set(out) and out["n_gpus"] == 1
+    assert out["check"] == "framebuffer rows identical to the oracle"
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and 0 < r["frac_blocking"] < 1
+    assert out["ms_per_frame_blocking"] > 0 and out["frame_ms_blocking"]["median"] > 0 and out["launch_ms_in_flight"]["frames"] == 10
+    assert "traffic" in r       # null unless a PMC summary of this very build is committed

@@ -71,7 +71,7 @@ def test_render_is_idempotent_and_variants_agree(renderer):
     scene = load_config("bunny")
     W, H = 3840, 2160
     frames = []
-    for variant in (0, 0, 1, 2, 3):
+    for variant in (0, 0, 1, 3, 26):
         _setup(renderer, scene, W, H, variant)
         renderer.render()
         frames.append(renderer.read_framebuffer())
@@ -287,7 +287,7 @@ def test_more_than_64_objects(renderer):
     scene.update_objects()
     W, H = 400, 224
     opx, orgb, _ = oracle_ffi.render(scene, W, H)
-    for variant in (0, 3, 31, 1):
+    for variant in (0, 3, 26, 1):
         _setup(renderer, scene, W, H, variant)
         renderer.set_debug_rgb(True)
         renderer.render()
@@ -579,7 +579,8 @@ def test_frame_sharder_with_virtual_ranks_on_one_gpu(monkeypatch, world, root_ru
             for rank in list(range(1, world)) + [0]:         # the root last: its gather call completes the exchange
                 state["rank"] = rank
                 ranks[rank][1].render_and_gather(scene)
-            torch.cuda.synchronize()
+            # no device synchronisation between frames: buffer reuse and the order of rendering, exchange and reassembly
+            # are carried by the sharder's events alone (the fake gather orders by events too), as in a real run
         for rank in list(range(1, world)) + [0]:
             state["rank"] = rank
             ranks[rank][1].flush()

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """SIMD utilisation of the octree-walk loops (diagnostic kernel variant 7)."""
 import os, sys
+# the diagnostic kernels live in the diagnostics build only: make -C relativitypathtracer_amd/csrc diag
+os.environ.setdefault("RPT_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "relativitypathtracer_amd", "librpt_hip_diag.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from relativitypathtracer_amd import Scene
 from relativitypathtracer_amd.renderer import Renderer

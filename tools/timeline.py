@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-wavefront timeline of one frame (diagnostic kernel variant 11): where is the critical path?"""
 import os, sys
+# the diagnostic kernels live in the diagnostics build only: make -C relativitypathtracer_amd/csrc diag
+os.environ.setdefault("RPT_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "relativitypathtracer_amd", "librpt_hip_diag.so"))
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from relativitypathtracer_amd import Scene
