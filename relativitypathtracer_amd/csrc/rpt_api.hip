@@ -55,6 +55,7 @@ struct rpt_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    hipEvent_t last_event = nullptr;                  // the event recorded last on `stream` (a launch's end or a staging copy's)
     std::string error;
 
     DeviceBuffer objects;
@@ -573,6 +574,7 @@ int rpt_set_objects(rpt_ctx *ctx, const void *objects, int count) {
         build_rects(ctx, (const rpt_object *)objects, count, (rptb::Rect *)(slot + bytes + (size_t)count * sizeof(rptd::DObj)));
         RPT_HIP(ctx, hipMemcpyAsync(ctx->objects.ptr, slot, bytes + dbytes, hipMemcpyHostToDevice, ctx->stream));
         RPT_HIP(ctx, hipEventRecord(ctx->staging_done[k], ctx->stream));
+        ctx->last_event = ctx->staging_done[k];
         ctx->staging_used |= 1u << k;
         ctx->staging_next++;
     }
@@ -625,7 +627,7 @@ int rpt_set_stream(rpt_ctx *ctx, void *hip_stream) {
     // drain what this context has enqueued on the stream it is leaving.  If that is an external stream the caller has
     // destroyed in the meantime, the handle is dead: the context's last launch is then waited for through its event.
     if (ctx->stream == ctx->own_stream) RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    else if (ctx->frame_rendered) RPT_HIP(ctx, hipEventSynchronize(ctx->ev_end));
+    else if (ctx->last_event) RPT_HIP(ctx, hipEventSynchronize(ctx->last_event));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return RPT_OK;
 }
@@ -669,6 +671,7 @@ int rpt_render_async(rpt_ctx *ctx) {
     RPT_HIP(ctx, hipEventRecord(eb, ctx->stream));
     if (int rc = launch(ctx)) return rc;
     RPT_HIP(ctx, hipEventRecord(ee, ctx->stream));
+    ctx->last_event = ee;
     if (timed) ctx->timing_frames++;
     else if (ctx->timing_frames >= 0) return fail(ctx, RPT_ERR_STATE, "timing region is full");
     ctx->frame_rendered = true;
