@@ -413,6 +413,8 @@ int launch(rpt_ctx *ctx) {
     case 40: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w4, grid, dim3(256), 0, ctx->stream, a); break;
     case 41: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w5, grid, dim3(256), 0, ctx->stream, a); break;
     case 42: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w6, grid, dim3(256), 0, ctx->stream, a); break;
+    case 44: hipLaunchKernelGGL(rptd::rpt_render_kernel_phases_w4, grid, dim3(256), 0, ctx->stream, a); break;
+    case 45: hipLaunchKernelGGL(rptd::rpt_render_kernel_phases_w5, grid, dim3(256), 0, ctx->stream, a); break;
 #ifdef RPT_DIAGNOSTICS
     case 7:
         if (int rc = reserve(ctx, ctx->counters, 16 * sizeof(unsigned long long))) return rc;
@@ -649,7 +651,7 @@ int rpt_object_screen_rect(const void *object, int interval, const float *root_b
 int rpt_set_variant(rpt_ctx *ctx, int variant) {
     if (!ctx) return RPT_ERR_ARG;
     switch (variant) {
-    case 0: case 1: case 3: case 26: case 40: case 41: case 42: break;
+    case 0: case 1: case 3: case 26: case 40: case 41: case 42: case 44: case 45: break;
 #ifdef RPT_DIAGNOSTICS
     case 7: case 8: case 11: break;
 #endif
