@@ -21,6 +21,9 @@
 
 #pragma clang fp contract(off)
 
+// rpt_relaxed.hip: the opt-in build of the same kernels with OpenCL's default arithmetic (variants 50 / 51)
+extern "C" int rpt_launch_relaxed_kernel(int waves_per_simd, const void *args, size_t args_bytes, unsigned grid_x, unsigned grid_y, void *stream);
+
 #define RPT_STAGING_SLOTS 4
 
 namespace {
@@ -413,8 +416,10 @@ int launch(rpt_ctx *ctx) {
     case 40: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w4, grid, dim3(256), 0, ctx->stream, a); break;
     case 41: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w5, grid, dim3(256), 0, ctx->stream, a); break;
     case 42: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w6, grid, dim3(256), 0, ctx->stream, a); break;
-    case 44: hipLaunchKernelGGL(rptd::rpt_render_kernel_phases_w4, grid, dim3(256), 0, ctx->stream, a); break;
-    case 45: hipLaunchKernelGGL(rptd::rpt_render_kernel_phases_w5, grid, dim3(256), 0, ctx->stream, a); break;
+    case 50:
+    case 51:
+        if (rpt_launch_relaxed_kernel(v == 51 ? 6 : 5, &a, sizeof a, grid.x, grid.y, (void *)ctx->stream)) return fail(ctx, RPT_ERR_DEVICE, "relaxed-arithmetic kernel launch failed");
+        break;
 #ifdef RPT_DIAGNOSTICS
     case 7:
         if (int rc = reserve(ctx, ctx->counters, 16 * sizeof(unsigned long long))) return rc;
@@ -651,7 +656,7 @@ int rpt_object_screen_rect(const void *object, int interval, const float *root_b
 int rpt_set_variant(rpt_ctx *ctx, int variant) {
     if (!ctx) return RPT_ERR_ARG;
     switch (variant) {
-    case 0: case 1: case 3: case 26: case 40: case 41: case 42: case 44: case 45: break;
+    case 0: case 1: case 3: case 26: case 40: case 41: case 42: case 50: case 51: break;
 #ifdef RPT_DIAGNOSTICS
     case 7: case 8: case 11: break;
 #endif

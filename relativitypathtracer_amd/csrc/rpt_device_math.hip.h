@@ -8,7 +8,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifdef RPT_RELAXED_FP
+#pragma clang fp contract(fast)      /* rpt_relaxed.hip only: the opt-in "OpenCL-conformant arithmetic" build of the same source */
+#else
 #pragma clang fp contract(off)
+#endif
 
 #define RPT_DEV __device__ __forceinline__
 

@@ -17,7 +17,11 @@
 #include "../../include/rpt_layout.h"
 #include "rpt_device_math.hip.h"
 
+#ifdef RPT_RELAXED_FP
+#pragma clang fp contract(fast)      /* rpt_relaxed.hip only: the opt-in "OpenCL-conformant arithmetic" build of the same source */
+#else
 #pragma clang fp contract(off)
+#endif
 
 namespace rptd {
 
@@ -462,124 +466,6 @@ RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &
     return true;
 }
 
-// The same walk as a per-lane state machine (derived layouts).  In octree_core every leaf step runs three loops back
-// to back — descend, test the leaf's triangles, leave — and each loop runs for as long as its slowest lane needs, so the
-// wave executes (sum over leaf steps of the per-step MAXIMUM trip counts).  Here every lane carries its own phase —
-// D: descend one level, T: test one triangle, X: leave the leaf and enter the neighbour — and each turn of the single loop
-// runs ONE phase, the one most lanes are waiting for (three __ballots + popcounts pick it, wave-uniformly); lanes in other
-// phases sit that turn out.  A lane's own sequence of nodes, triangles and hit updates is exactly that of octree_core, so
-// the results are identical; what changes is that lanes with many triangles in one leaf and lanes with many empty leaves
-// no longer wait for each other step by step, and the wave's trip count moves towards the maximum over lanes of the SUMS.
-RPT_DEV bool octree_core_phases(const KernelArgs &a, const rpt_object &obj, const Ray &newRay, f3 world_origin, float world_dirlen, Hit &hit) {
-    NodeRef<1> node;
-    int currOctreeIndex = obj.meshIndex;
-    node.load(a, currOctreeIndex);
-    f2 d;
-    int closeSide, farSide;
-    f3 nmin = node.bmin(a), nmax = node.bmax(a);
-    bool alive = intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide);
-    f3 uv = newRay.origin + newRay.dir * d.x;
-    if (alive && d.x < 0) {   // ray starts inside the root: descend to the leaf holding the origin
-        uv = (newRay.origin - nmin) / (nmax - nmin);
-        while (!node.is_leaf(a)) {
-            const int childIndex = octree_child_step_fast(uv);
-            currOctreeIndex = node.child(a, childIndex);
-            node.load(a, currOctreeIndex);
-        }
-        nmin = node.bmin(a);
-        nmax = node.bmax(a);
-        alive = intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide);
-        uv = newRay.origin + newRay.dir * d.x;
-    }
-    const ExitPlan plan = makeExitPlan(normalize(newRay.dir / (nmax - nmin)));
-    bool didHit = false;
-    int hitTri = 0;
-    int steps = 0;
-    int k = 0, kend = 0;
-    enum { PH_D = 0, PH_T = 1, PH_X = 2, PH_DONE = 3 };
-    int ph = PH_DONE;
-    // entering node `currOctreeIndex` (the head of octree_core's while loop): load, normalise uv, pick the next phase
-    auto enter = [&]() {
-        if (++steps > RPT_MAX_LEAF_STEPS) { ph = PH_DONE; return; }
-        node.load(a, currOctreeIndex);
-        nmin = node.bmin(a);
-        nmax = node.bmax(a);
-        uv = (uv - nmin) / (nmax - nmin);
-        if (node.is_leaf(a)) {
-            k = node.tri_begin(a);
-            kend = k + node.tri_count(a);
-            ph = k < kend ? PH_T : PH_X;
-        } else {
-            ph = PH_D;
-        }
-    };
-    if (alive) enter();
-    while (true) {
-        const unsigned long long mD = __ballot(ph == PH_D), mT = __ballot(ph == PH_T), mX = __ballot(ph == PH_X);
-        if ((mD | mT | mX) == 0ull) break;
-        const int nD = __popcll(mD), nT = __popcll(mT), nX = __popcll(mX);
-        if (nT >= nD && nT >= nX) {
-            if (ph == PH_T) {
-                f3 A, v0v1, v0v2;
-                int tri;
-                node.tri(a, k, A, v0v1, v0v2, tri);
-                float dist;
-                f2 triUV;
-                if (intersect_triangle_edges(A, v0v1, v0v2, newRay, dist, triUV)) {
-                    if (0 <= dist && dist < hit.dist) {
-                        hitTri = tri;
-                        hit.dist = dist;
-                        hit.uv = triUV;
-                        didHit = true;
-                    }
-                }
-                if (++k >= kend) ph = PH_X;
-            }
-        } else if (nD >= nX) {
-            if (ph == PH_D) {
-                const int childIndex = octree_child_step_fast(uv);
-                currOctreeIndex = node.child(a, childIndex);
-                node.load(a, currOctreeIndex);
-                if (node.is_leaf(a)) {
-                    nmin = node.bmin(a);
-                    nmax = node.bmax(a);
-                    k = node.tri_begin(a);
-                    kend = k + node.tri_count(a);
-                    ph = k < kend ? PH_T : PH_X;
-                }
-            }
-        } else {
-            if (ph == PH_X) {
-                const f3 extents = nmax - nmin;
-                farSide = getOppositeBoxSide(plan, uv);
-                uv = nmin + uv * extents;
-                currOctreeIndex = node.neighbor(a, farSide);
-                const f3 v = uv - newRay.origin;
-                const bool stop = didHit ? (length(v) > hit.dist) : (hit.dist == 1e20f ? dot(v, v) == __builtin_inff() : length(v) > hit.dist);
-                if (stop || currOctreeIndex == -1) ph = PH_DONE;
-                else enter();
-            }
-        }
-    }
-    if (!didHit) return false;
-
-    const float u = hit.uv.x, v = hit.uv.y;
-    const float w = 1.0f - u - v;
-    const f3 normA = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 0]]);
-    const f3 normB = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 1]]);
-    const f3 normC = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 2]]);
-    hit.normal = normalize(applyTranspose(obj.InvM, normA * w + normB * u + normC * v));
-    const rpt_float2 uvA = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 0]];
-    const rpt_float2 uvB = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 1]];
-    const rpt_float2 uvC = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 2]];
-    hit.uv.x = w * uvA.x + u * uvB.x + v * uvC.x;
-    hit.uv.y = w * uvA.y + u * uvB.y + v * uvC.y;
-    const f3 objPoint = newRay.origin + newRay.dir * hit.dist;
-    const f3 worldPoint = transformPoint(obj.M, objPoint);
-    hit.dist = length(worldPoint - world_origin) / world_dirlen;
-    return true;
-}
-
 RPT_DEV float max3(f3 v) { return cl_max(cl_max(v.x, v.y), v.z); }   // opencl_kernel.cl:310
 RPT_DEV float cube_winding(f3 origin) {
     return max3(mk3(__builtin_fabsf(origin.x), __builtin_fabsf(origin.y), __builtin_fabsf(origin.z))) < 1.0f ? -1.0f : 1.0f;
@@ -652,7 +538,6 @@ RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, H
         Ray newRay;
         newRay.origin = origin;
         newRay.dir = dir;
-        if (V == 21) return octree_core_phases(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
         return octree_core<V>(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
     }
     default:
@@ -682,7 +567,6 @@ RPT_DEV bool intersect_object_primary(const KernelArgs &a, int i, f4 rayDir, Hit
         newRay.origin = origin;
         newRay.dir = dir;
         const f3 cam3 = mk3(obj.stationaryCam.y, obj.stationaryCam.z, obj.stationaryCam.w);
-        if (V == 21) return octree_core_phases(a, obj, newRay, cam3, length(d3), hit);
         return octree_core<V>(a, obj, newRay, cam3, length(d3), hit);
     }
     default:
@@ -934,6 +818,7 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
     }
 }
 
+#ifndef RPT_RELAXED_FP    /* rpt_relaxed.hip instantiates its own two kernels and nothing else from here on */
 // Product kernels (rpt_set_variant): the default, the general fallback and the A/B forms kept for measurement.
 __global__ __launch_bounds__(256) void rpt_render_kernel_v0(const KernelArgs a) { render_pixel_body<0>(a); }                                                            // 1
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_w4(const KernelArgs a) { render_pixel_body<1>(a); }           // 3
@@ -942,9 +827,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_ballot_w4(const KernelArgs a) { render_pixel_body<20>(a); }       // 40
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_w5(const KernelArgs a) { render_pixel_body<20>(a); }       // 41 = default
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_ballot_w6(const KernelArgs a) { render_pixel_body<20>(a); }       // 42
-// V = 21: 20 + the octree walk as a per-lane state machine (octree_core_phases)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_phases_w4(const KernelArgs a) { render_pixel_body<21>(a); }       // 44
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_phases_w5(const KernelArgs a) { render_pixel_body<21>(a); }       // 45
 #ifdef RPT_DIAGNOSTICS   /* librpt_hip_diag.so only (make diag): loop counters, primary rays only, per-wave timeline */
 __global__ __launch_bounds__(256) void rpt_render_kernel_v1_diag(const KernelArgs a) { render_pixel_body<2>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_timeline(const KernelArgs a) { render_pixel_body<4>(a); }
@@ -1152,5 +1034,7 @@ __global__ void rpt_probe_kernel(int which, const float *in, float *out, int n) 
         out[12 * i + 8] = (float)cb; out[12 * i + 9] = b.x; out[12 * i + 10] = b.y; out[12 * i + 11] = b.z;
     }
 }
+
+#endif  /* !RPT_RELAXED_FP */
 
 }  // namespace rptd
