@@ -384,6 +384,8 @@ int launch(rpt_ctx *ctx) {
     }
     a.ambient = ctx->ambient;
     a.aspect = (float)ctx->width / (float)ctx->height;
+    a.inv_width = 1.0f / (float)ctx->width;
+    a.inv_height = 1.0f / (float)ctx->height;
     a.object_count = ctx->object_count;
     a.width = ctx->width;
     a.height = ctx->height;

@@ -93,6 +93,7 @@ struct KernelArgs {
     unsigned long long *tile_masks;          // [n_tiles] bit i = primary rays of the tile may hit object i (i < 64)
     // per-object image-plane rectangles (rpt_screen_bounds.hpp), tested lane-parallel by each wavefront (V >= 20)
     const float4 *rects;                     // [object_count] u0, v0, u1, v1 on the plane z = 0.5
+    float inv_width, inv_height;             // 1/width, 1/height (for the cull only: approximate is fine there)
 };
 
 struct Hit {                 // opencl_kernel.cl:38-44
@@ -737,14 +738,15 @@ RPT_DEV uint32_t tonemap_pack(const KernelArgs &a, f3 color, f3 &mapped) {
 // ((x/W - 0.5) * aspect, y/H - 0.5) (opencl_kernel.cl:57-63).  NaNs compare false, so a broken rectangle keeps its object.
 RPT_DEV unsigned long long wave_object_mask(const KernelArgs &a, int tile_x0, int tile_y0) {
     const int lane = threadIdx.x & 63;
-    bool keep = false;
-    if (lane < a.object_count) {
-        const float4 r = a.rects[lane];
-        const float iw = 1.0f / (float)a.width, ih = 1.0f / (float)a.height;
-        const float tu0 = (((float)tile_x0 - 1.5f) * iw - 0.5f) * a.aspect, tu1 = (((float)tile_x0 + 8.5f) * iw - 0.5f) * a.aspect;
-        const float tv0 = ((float)tile_y0 - 1.5f) * ih - 0.5f, tv1 = ((float)tile_y0 + 8.5f) * ih - 0.5f;
-        keep = !(r.z < tu0 || r.x > tu1 || r.w < tv0 || r.y > tv1);
-    }
+    // one 16-B load per lane, issued unconditionally (lanes beyond the object count re-read rectangle 0: always a valid
+    // address when there is any object), and four compares without branches: one memory round trip, no divergence
+    const int n = a.object_count;
+    const float4 r = a.rects[(lane < n) ? lane : 0];
+    const float iw = a.inv_width, ih = a.inv_height;
+    const float tu0 = (((float)tile_x0 - 1.5f) * iw - 0.5f) * a.aspect, tu1 = (((float)tile_x0 + 8.5f) * iw - 0.5f) * a.aspect;
+    const float tv0 = ((float)tile_y0 - 1.5f) * ih - 0.5f, tv1 = ((float)tile_y0 + 8.5f) * ih - 0.5f;
+    const bool outside = (r.z < tu0) | (r.x > tu1) | (r.w < tv0) | (r.y > tv1);
+    const bool keep = (lane < n) & !outside;
     return __ballot(keep);
 }
 
