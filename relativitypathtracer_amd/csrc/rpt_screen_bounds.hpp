@@ -134,6 +134,7 @@ inline DirMap make_map(const rpt_object &o, int interval) {
 // Accumulates the image-plane bounding box of a sampled closed or open curve of object-space directions.
 struct Accum {
     const DirMap &m;
+    Accum &operator=(const Accum &o) { u0 = o.u0; v0 = o.v0; u1 = o.u1; v1 = o.v1; failed = o.failed; any_front = o.any_front; any_near_behind = o.any_near_behind; n_crossings = o.n_crossings; return *this; }
     double u0 = 1e300, v0 = 1e300, u1 = -1e300, v1 = -1e300;
     bool failed = false, any_front = false, any_near_behind = false;
     int n_crossings = 0;
@@ -275,8 +276,8 @@ inline Rect box_rect(const rpt_object &o, int interval, const double bmin[3], co
         seen_lo[a] = p[a] < lo[a] - tol ? 1 : (p[a] > lo[a] + tol ? -1 : 0);
         seen_hi[a] = p[a] > hi[a] + tol ? 1 : (p[a] < hi[a] - tol ? -1 : 0);
     }
-    const int S = m.linear ? 1 : 16;          // segments per edge: straight edges stay straight under a linear map; under
-                                              // aberration they become conic arcs, sampled densely (and see crossing())
+    int S = m.linear ? 1 : 8;                 // segments per edge: straight edges stay straight under a linear map; under
+                                              // aberration they become conic arcs: 8 segments, 16 when the outline is clipped
     // the eight corners are mapped once (corner k: bit 0/1/2 = x/y/z at hi); the first and the last one are pushed
     // through F again, which is where a wrong inverse would show
     D3 cu[8], cnd[8];
@@ -286,6 +287,7 @@ inline Rect box_rect(const rpt_object &o, int interval, const double bmin[3], co
     }
     Accum acc(m);
     bool clipped = false;
+resample:
     for (int axis = 0; axis < 3 && !acc.failed; axis++) {
         const int b = (axis + 1) % 3, c = (axis + 2) % 3;
         for (int corner = 0; corner < 4 && !acc.failed; corner++) {
@@ -311,6 +313,11 @@ inline Rect box_rect(const rpt_object &o, int interval, const double bmin[3], co
         }
     }
     if (acc.failed) return full_rect();
+    if (clipped && !m.linear && S < 16) {      // an outline that runs off to the horizon bends hardest there: sample it again, finer
+        S = 16;
+        acc = Accum(m);
+        goto resample;
+    }
     // the horizon: coarse when the whole outline is in front of the camera (it then only guards against a region that
     // wraps around behind the camera, which strong aberration can produce), fine when the outline is clipped
     double blo[3], bhi[3];
@@ -321,7 +328,7 @@ inline Rect box_rect(const rpt_object &o, int interval, const double bmin[3], co
     } else {
         acc.horizon(32, inside_box);
     }
-    return finish(acc, m.linear ? 0.002 : 0.015);
+    return finish(acc, m.linear ? 0.002 : 0.025);
 }
 
 // Unit sphere at the object-space origin.
