@@ -67,6 +67,9 @@ struct rpt_ctx {
     DeviceBuffer tile_masks;                          // per-tile object masks of the prepass
     std::vector<uint8_t> host_objects;                // last Object[] (DObj depends on `interval`: rebuilt when it changes)
     DeviceBuffer dobjs;
+    std::vector<rptb::Rect> rects;                    // last frame's per-object rectangles (reused for unchanged objects)
+    int rect_interval = 0x7fffffff;
+    const void *rect_geo = nullptr;
     DeviceBuffer owned_out, owned_plane, owned_rgb;
     void *pinned_objects = nullptr;                   // RPT_STAGING_SLOTS pinned slots of Object[] + DObj[]
     size_t pinned_capacity = 0;
@@ -292,15 +295,24 @@ void build_dobjs(const rpt_ctx *ctx, const rpt_object *objs, int count, rptd::DO
     }
 }
 
-// Per-frame image-plane rectangle of every object (rpt_screen_bounds.hpp) for the in-kernel lane-parallel cull.
-void build_rects(const rpt_ctx *ctx, const rpt_object *objs, int count, rptb::Rect *out) {
+// Per-frame image-plane rectangle of every object (rpt_screen_bounds.hpp) for the in-kernel lane-parallel cull.  A
+// rectangle is a pure function of the object's 320 bytes, the interval and (meshes) the root bounds: an object whose
+// record is byte-identical to the previous frame's (a camera at rest, a paused scene) keeps its rectangle.
+void build_rects(rpt_ctx *ctx, const rpt_object *objs, int count, rptb::Rect *out) {
+    const bool comparable = ctx->rect_interval == ctx->interval && ctx->rect_geo == ctx->geo.get() &&
+                            ctx->rects.size() == (size_t)count && ctx->host_objects.size() == (size_t)count * sizeof(rpt_object);
+    const rpt_object *prev = comparable ? (const rpt_object *)ctx->host_objects.data() : nullptr;
+    ctx->rects.resize((size_t)count);
     for (int i = 0; i < count; i++) {
         const rpt_object &o = objs[i];
+        if (prev && std::memcmp(&prev[i], &o, sizeof o) == 0) { out[i] = ctx->rects[i]; continue; }
         const float *root = nullptr;
         if (o.type == RPT_MESH && o.meshIndex >= 0 && (size_t)o.meshIndex * 6 + 5 < ctx->geo->host_node_bounds.size())
             root = &ctx->geo->host_node_bounds[(size_t)o.meshIndex * 6];
-        out[i] = rptb::object_rect(o, ctx->interval, root);
+        out[i] = ctx->rects[i] = rptb::object_rect(o, ctx->interval, root);
     }
+    ctx->rect_interval = ctx->interval;
+    ctx->rect_geo = ctx->geo.get();
 }
 
 int validate_objects(rpt_ctx *ctx, const rpt_object *objs, int count) {
