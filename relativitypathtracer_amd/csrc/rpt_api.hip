@@ -430,6 +430,33 @@ int launch(rpt_ctx *ctx) {
     case 40: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w4, grid, dim3(256), 0, ctx->stream, a); break;
     case 41: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w5, grid, dim3(256), 0, ctx->stream, a); break;
     case 42: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w6, grid, dim3(256), 0, ctx->stream, a); break;
+    case 43: {   // 41 with the mesh region dispatched first (whole-frame contexts only)
+        a.first_w = 0;
+        if (ctx->first_tile == 0 && ctx->tile_step == 1 && ctx->run_log2 == 0 && ctx->rects.size() == (size_t)ctx->object_count) {
+            // union of the mesh objects' screen rectangles, in strips (32 px) and tile rows (8 px), grown by one
+            float u0 = 3e38f, v0 = 3e38f, u1 = -3e38f, v1 = -3e38f;
+            const rpt_object *objs = (const rpt_object *)ctx->host_objects.data();
+            for (int i = 0; i < ctx->object_count; i++)
+                if (objs[i].type == RPT_MESH && ctx->rects[i].u0 <= ctx->rects[i].u1) {
+                    u0 = std::min(u0, ctx->rects[i].u0); v0 = std::min(v0, ctx->rects[i].v0);
+                    u1 = std::max(u1, ctx->rects[i].u1); v1 = std::max(v1, ctx->rects[i].v1);
+                }
+            if (u0 <= u1) {
+                const float W = (float)ctx->width, H = (float)ctx->height;
+                auto clampi = [](float x, int lo, int hi) { return x < (float)lo ? lo : (x > (float)hi ? hi : (int)x); };
+                const int sx0 = clampi(std::floor((u0 / a.aspect + 0.5f) * W / 32.0f) - 1, 0, (int)grid.x - 1);
+                const int sx1 = clampi(std::floor((u1 / a.aspect + 0.5f) * W / 32.0f) + 1, 0, (int)grid.x - 1);
+                const int ty0 = clampi(std::floor((v0 + 0.5f) * H / 8.0f) - 1, 0, (int)grid.y - 1);
+                const int ty1 = clampi(std::floor((v1 + 0.5f) * H / 8.0f) + 1, 0, (int)grid.y - 1);
+                const long long area = (long long)(sx1 - sx0 + 1) * (ty1 - ty0 + 1);
+                if (sx1 >= sx0 && ty1 >= ty0 && sx1 - sx0 + 1 < (int)grid.x && area * 2 < (long long)grid.x * grid.y) {   // a proper part of the frame
+                    a.first_sx = sx0; a.first_ty = ty0; a.first_w = sx1 - sx0 + 1; a.first_h = ty1 - ty0 + 1;
+                }
+            }
+        }
+        hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_first_w5, grid, dim3(256), 0, ctx->stream, a);
+        break;
+    }
     case 50:
     case 51:
         if (rpt_launch_relaxed_kernel(v == 51 ? 6 : 5, &a, sizeof a, grid.x, grid.y, (void *)ctx->stream)) return fail(ctx, RPT_ERR_DEVICE, "relaxed-arithmetic kernel launch failed");
@@ -670,7 +697,7 @@ int rpt_object_screen_rect(const void *object, int interval, const float *root_b
 int rpt_set_variant(rpt_ctx *ctx, int variant) {
     if (!ctx) return RPT_ERR_ARG;
     switch (variant) {
-    case 0: case 1: case 3: case 26: case 40: case 41: case 42: case 50: case 51: break;
+    case 0: case 1: case 3: case 26: case 40: case 41: case 42: case 43: case 50: case 51: break;
 #ifdef RPT_DIAGNOSTICS
     case 7: case 8: case 11: break;
 #endif

@@ -94,6 +94,9 @@ struct KernelArgs {
     // per-object image-plane rectangles (rpt_screen_bounds.hpp), tested lane-parallel by each wavefront (V >= 20)
     const float4 *rects;                     // [object_count] u0, v0, u1, v1 on the plane z = 0.5
     float inv_width, inv_height;             // 1/width, 1/height (for the cull only: approximate is fine there)
+    // dispatch order (V == 23): the strips [first_sx, first_sx + first_w) x [first_ty, first_ty + first_h) — where the meshes
+    // are, i.e. where the frame's longest waves live — are handed out FIRST, the rest in natural order; first_w = 0: off
+    int first_sx, first_ty, first_w, first_h;
 };
 
 struct Hit {                 // opencl_kernel.cl:38-44
@@ -767,16 +770,43 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
         if ((threadIdx.x & 63) < 8) rpt_diag_lds[threadIdx.x >> 6][threadIdx.x & 63] = 0;
         rpt_diag_lds[threadIdx.x >> 6][6] = clock64();
     }
-    const int tile_row = (int)blockIdx.y;        // 8-row tiles of this context, natural order
+    int tile_row = (int)blockIdx.y;              // 8-row tiles of this context, natural order
+    int strip = (int)blockIdx.x;                 // 32-pixel-wide strip of that row
+    if (V == 23 && a.first_w > 0) {
+        // Workgroups are handed out in the order of their linear index.  One frame at a time, what ends the frame is the last of
+        // its long waves (a silhouette tile's walk lives 150 us), so the region that holds them goes first and everything
+        // else fills the machine behind it: linear index b -> region row-major, then the remaining strips in natural order.
+        const int SX = (int)gridDim.x, rw = a.first_w, rh = a.first_h;
+        int b = (int)blockIdx.y * SX + (int)blockIdx.x;
+        if (b < rw * rh) {
+            tile_row = a.first_ty + b / rw;
+            strip = a.first_sx + b % rw;
+        } else {
+            b -= rw * rh;
+            const int below = a.first_ty * SX, beside = rh * (SX - rw);
+            if (b < below) {
+                tile_row = b / SX;
+                strip = b % SX;
+            } else if (b - below < beside) {
+                const int r = b - below, c = r % (SX - rw);
+                tile_row = a.first_ty + r / (SX - rw);
+                strip = c < a.first_sx ? c : c + rw;
+            } else {
+                const int r = b - below - beside;
+                tile_row = a.first_ty + rh + r / SX;
+                strip = r % SX;
+            }
+        }
+    }
     const int row_in_tile = lane >> 3;
-    const int x_coord = (int)blockIdx.x * 32 + wave * 8 + (lane & 7);
+    const int x_coord = strip * 32 + wave * 8 + (lane & 7);
     const int local_row = tile_row * RPT_TILE_ROWS + row_in_tile;
     const int global_tile = (tile_row >> a.run_log2) * a.tile_step + a.first_tile + (tile_row & ((1 << a.run_log2) - 1));
     const int y_coord = global_tile * RPT_TILE_ROWS + row_in_tile;
     // the wave's object mask comes from a __ballot over ALL 64 lanes (lane i answers for object i), so it is formed
     // before the lanes of a partial tile leave
     unsigned long long object_mask = ~0ull;
-    if (V >= 20) object_mask = wave_object_mask(a, (int)blockIdx.x * 32 + wave * 8, global_tile * RPT_TILE_ROWS);
+    if (V >= 20) object_mask = wave_object_mask(a, strip * 32 + wave * 8, global_tile * RPT_TILE_ROWS);
     if (x_coord >= a.width || y_coord >= a.height) return;   // the reference has no guard (UB)
 
     f3 color;
@@ -829,6 +859,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_ballot_w4(const KernelArgs a) { render_pixel_body<20>(a); }       // 40
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_w5(const KernelArgs a) { render_pixel_body<20>(a); }       // 41 = default
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_ballot_w6(const KernelArgs a) { render_pixel_body<20>(a); }       // 42
+// V = 23: 20 + the strips that hold the meshes handed out first (dispatch order only)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_first_w5(const KernelArgs a) { render_pixel_body<23>(a); }   // 43
 #ifdef RPT_DIAGNOSTICS   /* librpt_hip_diag.so only (make diag): loop counters, primary rays only, per-wave timeline */
 __global__ __launch_bounds__(256) void rpt_render_kernel_v1_diag(const KernelArgs a) { render_pixel_body<2>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_timeline(const KernelArgs a) { render_pixel_body<4>(a); }
