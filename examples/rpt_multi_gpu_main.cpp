@@ -84,8 +84,9 @@ int main(int argc, char **argv) {
     for (int d = 0; d < n; d++) {
         devs[d] = d;
         CHECK(hipSetDevice(d));
+        const std::vector<int> slot_devices(kSlots, d);                 // the frame slots of GPU d: one context each
+        CHECK(rpt_create_multi(ctx[d].data(), slot_devices.data(), kSlots));
         for (int k = 0; k < kSlots; k++) {
-            CHECK(rpt_create(&ctx[d][k], d));
             CHECK(k == 0 ? rpt_upload_scene(ctx[d][0], &desc) : rpt_share_scene(ctx[d][k], ctx[d][0]));
             CHECK(rpt_set_params(ctx[d][k], wp, ambient, width, height, interval));
             if (!root_run) CHECK(rpt_set_rows(ctx[d][k], d, n, /*colour_plane=*/1));

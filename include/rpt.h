@@ -52,6 +52,10 @@ const char *rpt_version(void);
 /* Create a context on HIP device `device_ordinal` (replaces platform/device pick, context+queue
  * creation and the run-time program build: the gfx950 code object is prebuilt). */
 int rpt_create(rpt_ctx **out, int device_ordinal);
+/* One context per listed device (multi-GPU hosts: SURVEY.md §8b); all or nothing — on failure every context already
+ * created is destroyed, out[] is nulled and the first error is returned.  The same device may be listed more than once
+ * (frame slots). */
+int rpt_create_multi(rpt_ctx **out, const int *device_ordinals, int n);
 void rpt_destroy(rpt_ctx *ctx);
 const char *rpt_last_error(const rpt_ctx *ctx);
 

@@ -119,6 +119,7 @@ def scene_lib() -> C.CDLL:
 HIP_SYMBOLS = {
     # name: (restype, argtypes) — exactly the entry points include/rpt.h declares
     "rpt_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "rpt_create_multi": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]),
     "rpt_destroy": (None, [C.c_void_p]),
     "rpt_last_error": (C.c_char_p, [C.c_void_p]),
     "rpt_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),

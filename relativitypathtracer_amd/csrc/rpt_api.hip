@@ -514,6 +514,19 @@ int rpt_create(rpt_ctx **out, int device_ordinal) {
     return RPT_OK;
 }
 
+int rpt_create_multi(rpt_ctx **out, const int *device_ordinals, int n) {
+    if (!out || !device_ordinals || n <= 0) return RPT_ERR_ARG;
+    for (int i = 0; i < n; i++) out[i] = nullptr;
+    for (int i = 0; i < n; i++) {
+        const int rc = rpt_create(&out[i], device_ordinals[i]);
+        if (rc != RPT_OK) {
+            for (int k = 0; k < i; k++) { rpt_destroy(out[k]); out[k] = nullptr; }
+            return rc;
+        }
+    }
+    return RPT_OK;
+}
+
 void rpt_destroy(rpt_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);

@@ -778,11 +778,15 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
         // else fills the machine behind it: linear index b -> region row-major, then the remaining strips in natural order.
         const int SX = (int)gridDim.x, rw = a.first_w, rh = a.first_h;
         int b = (int)blockIdx.y * SX + (int)blockIdx.x;
-        if (b < rw * rh) {
+        // the region's strips are dealt out alternately with the others (the host makes sure the others are the majority):
+        // the long waves start at once, and short ones share their SIMDs
+        bool in_region;
+        if (b < 2 * rw * rh) { in_region = (b & 1) == 0; b >>= 1; }
+        else { in_region = false; b -= rw * rh; }
+        if (in_region) {
             tile_row = a.first_ty + b / rw;
             strip = a.first_sx + b % rw;
         } else {
-            b -= rw * rh;
             const int below = a.first_ty * SX, beside = rh * (SX - rw);
             if (b < below) {
                 tile_row = b / SX;
