@@ -431,7 +431,7 @@ int launch(rpt_ctx *ctx) {
     case 41: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w5, grid, dim3(256), 0, ctx->stream, a); break;
     case 42: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w6, grid, dim3(256), 0, ctx->stream, a); break;
     case 43: {   // 41 with the mesh region dispatched first (whole-frame contexts only)
-        a.first_w = 0;
+        a.first_w = 0; a.first_h = 0;
         if (ctx->first_tile == 0 && ctx->tile_step == 1 && ctx->run_log2 == 0 && ctx->rects.size() == (size_t)ctx->object_count) {
             // union of the mesh objects' screen rectangles, in strips (32 px) and tile rows (8 px), grown by one
             float u0 = 3e38f, v0 = 3e38f, u1 = -3e38f, v1 = -3e38f;
@@ -449,7 +449,8 @@ int launch(rpt_ctx *ctx) {
                 const int ty0 = clampi(std::floor((v0 + 0.5f) * H / 8.0f) - 1, 0, (int)grid.y - 1);
                 const int ty1 = clampi(std::floor((v1 + 0.5f) * H / 8.0f) + 1, 0, (int)grid.y - 1);
                 const long long area = (long long)(sx1 - sx0 + 1) * (ty1 - ty0 + 1);
-                if (sx1 >= sx0 && ty1 >= ty0 && sx1 - sx0 + 1 < (int)grid.x && area * 2 < (long long)grid.x * grid.y) {   // a proper part of the frame
+                (void)area;
+                if (ty1 >= ty0 && ty0 > 0 && (ty1 - ty0 + 1) * 2 < (int)grid.y) {   // a band that does not already start the frame, at most half of it
                     a.first_sx = sx0; a.first_ty = ty0; a.first_w = sx1 - sx0 + 1; a.first_h = ty1 - ty0 + 1;
                 }
             }

@@ -772,35 +772,12 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
     }
     int tile_row = (int)blockIdx.y;              // 8-row tiles of this context, natural order
     int strip = (int)blockIdx.x;                 // 32-pixel-wide strip of that row
-    if (V == 23 && a.first_w > 0) {
-        // Workgroups are handed out in the order of their linear index.  One frame at a time, what ends the frame is the last of
-        // its long waves (a silhouette tile's walk lives 150 us), so the region that holds them goes first and everything
-        // else fills the machine behind it: linear index b -> region row-major, then the remaining strips in natural order.
-        const int SX = (int)gridDim.x, rw = a.first_w, rh = a.first_h;
-        int b = (int)blockIdx.y * SX + (int)blockIdx.x;
-        // the region's strips are dealt out alternately with the others (the host makes sure the others are the majority):
-        // the long waves start at once, and short ones share their SIMDs
-        bool in_region;
-        if (b < 2 * rw * rh) { in_region = (b & 1) == 0; b >>= 1; }
-        else { in_region = false; b -= rw * rh; }
-        if (in_region) {
-            tile_row = a.first_ty + b / rw;
-            strip = a.first_sx + b % rw;
-        } else {
-            const int below = a.first_ty * SX, beside = rh * (SX - rw);
-            if (b < below) {
-                tile_row = b / SX;
-                strip = b % SX;
-            } else if (b - below < beside) {
-                const int r = b - below, c = r % (SX - rw);
-                tile_row = a.first_ty + r / (SX - rw);
-                strip = c < a.first_sx ? c : c + rw;
-            } else {
-                const int r = b - below - beside;
-                tile_row = a.first_ty + rh + r / SX;
-                strip = r % SX;
-            }
-        }
+    if (V == 23 && a.first_h > 0) {
+        // Workgroups are handed out in the order of their linear index, i.e. row of strips by row of strips.  One frame at a
+        // time, what ends the frame is the last of its long waves, so the band of tile rows that holds the meshes goes first
+        // (whole rows, in their natural order: neighbours stay neighbours) and the other rows follow in order.
+        const int y = (int)blockIdx.y, rh = a.first_h;
+        tile_row = y < rh ? a.first_ty + y : (y - rh < a.first_ty ? y - rh : y);
     }
     const int row_in_tile = lane >> 3;
     const int x_coord = strip * 32 + wave * 8 + (lane & 7);
