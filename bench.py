@@ -42,7 +42,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-DEFAULT_KERNEL = "rpt_render_kernel_ballot_w5"   # what variant 0 launches (csrc/rpt_api.hip)
+DEFAULT_KERNEL = "rpt_render_kernel_ballot_w5 (rpt_render_async; the blocking rpt_render launches the same kernel with the mesh rows first)"   # what variant 0 launches (csrc/rpt_api.hip)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md): the contract roofline for this path
 
 WORKLOADS = {

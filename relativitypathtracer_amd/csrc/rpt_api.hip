@@ -94,6 +94,7 @@ struct rpt_ctx {
     int variant = 0;
     float last_ms = 0.0f;
     bool frame_rendered = false;
+    bool latency_call = false;                        // the launch in progress comes from the blocking rpt_render()
 };
 
 namespace {
@@ -411,7 +412,10 @@ int launch(rpt_ctx *ctx) {
     const dim3 grid((ctx->width + 31) / 32, tiles);
     // variant 0 = default: the derived-layout per-pixel kernel whose wavefronts build their own object masks from the
     // per-object screen rectangles (41), 5 waves per SIMD, when the octree allows the derived layout; else the general kernel (1)
-    int v = ctx->variant == 0 ? 41 : ctx->variant;
+    // The blocking rpt_render() is a latency call: the caller waits for this frame, so the band of tile rows that holds the
+    // meshes — where the frame's longest waves live — is dispatched first (43; 2-12 % less latency).
+    // rpt_render_async() is a throughput call (frames in flight fill each other's gaps): natural order (41).
+    int v = ctx->variant == 0 ? (ctx->latency_call ? 43 : 41) : ctx->variant;
     if (!ctx->geo->compact_ok) v = 1;
     switch (v) {
     case 1: hipLaunchKernelGGL(rptd::rpt_render_kernel_v0, grid, dim3(256), 0, ctx->stream, a); break;
@@ -797,7 +801,11 @@ int rpt_sync(rpt_ctx *ctx) {
 }
 
 int rpt_render(rpt_ctx *ctx) {
-    if (int rc = rpt_render_async(ctx)) return rc;
+    if (!ctx) return RPT_ERR_ARG;
+    ctx->latency_call = true;
+    const int rc = rpt_render_async(ctx);
+    ctx->latency_call = false;
+    if (rc) return rc;
     return rpt_sync(ctx);
 }
 
