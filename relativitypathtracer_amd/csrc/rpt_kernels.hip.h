@@ -524,11 +524,28 @@ RPT_DEV bool sphere_core(const rpt_object &obj, f3 rayToSphere, float c, f3 dir,
 
 // One object against one ray given as a 4-D event + 4-D direction in the object's rest frame
 // (the general form: shadow rays, and primary rays of the V = 0 kernel).
+// seg_max > 0 (shadow rays, V == 24): the caller only asks whether the object is hit at a distance below seg_max
+// (sample_light: dist < lightDist).  A hit at distance s lies at origin + dir * s (dir not yet normalised: hit.dist is
+// measured in its units, opencl_kernel.cl:328,354) ON the object, and a sphere's or a cube's surface lies inside [-1,1]^3:
+// if, for every active lane of the wave, the segment origin + dir * [0, seg_max] stays on one side of one of the cube's six
+// planes (a bounding-box test of the segment: three multiply-adds and twelve compares, margins for rounding, NaNs keep the
+// object), no lane can get an answer other than "not hit below seg_max", and the normalisation, its three IEEE
+// divisions and the intersector are skipped for the whole wave.  Meshes are left alone: the reference's walk accepts a
+// triangle where the ray meets its plane, which for another mesh's triangle in the leaf's list (Mesh.cpp:16-19) can be
+// outside the octree's box.
 template <int V>
-RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, Hit &hit) {
+RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, Hit &hit, float seg_max = -1.0f) {
     const rpt_object &obj = a.objects[i];
     const f3 origin = transformPoint(obj.InvM, yzw(origin4));
     f3 dir = transformDirection(obj.InvM, yzw(dir4));
+    if (V == 24 && seg_max > 0.0f && obj.type != RPT_MESH) {
+        const float s = seg_max * 1.001f + 1.0e-4f, m = 1.002f;
+        const f3 e = origin + dir * s;
+        const bool apart = ((origin.x > m) & (e.x > m)) | ((origin.x < -m) & (e.x < -m)) |
+                           ((origin.y > m) & (e.y > m)) | ((origin.y < -m) & (e.y < -m)) |
+                           ((origin.z > m) & (e.z > m)) | ((origin.z < -m) & (e.z < -m));
+        if (__ballot(!apart) == 0ull) return false;
+    }
     const float scale = length(dir);
     dir = dir / scale;
     switch (obj.type) {
@@ -624,7 +641,7 @@ RPT_DEV bool sample_light_occluded(const KernelArgs &a, f4 origin4, f4 dir4, flo
             newHit.dist = 1e20f;
             const f4 newEvent0 = transformPoint4D(a.objects[i].Lorentz, origin4);
             const f4 lightDir = transformPoint4D(a.objects[i].Lorentz, lightDir0);
-            if (intersect_object<V>(a, i, newEvent0, lightDir, newHit)) {
+            if (intersect_object<V>(a, i, newEvent0, lightDir, newHit, lightDist)) {
                 if (newHit.dist < lightDist) return true;
             }
         }
@@ -840,6 +857,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_ballot_w4(const KernelArgs a) { render_pixel_body<20>(a); }       // 40
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_w5(const KernelArgs a) { render_pixel_body<20>(a); }       // 41 = default
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_ballot_w6(const KernelArgs a) { render_pixel_body<20>(a); }       // 42
+// V = 24: 20 + shadow rays skip, wave-wide, spheres and cubes whose unit box the segment to the light cannot reach
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_seg_w5(const KernelArgs a) { render_pixel_body<24>(a); }   // 44
 // V = 23: 20 + the strips that hold the meshes handed out first (dispatch order only)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_first_w5(const KernelArgs a) { render_pixel_body<23>(a); }   // 43
 #ifdef RPT_DIAGNOSTICS   /* librpt_hip_diag.so only (make diag): loop counters, primary rays only, per-wave timeline */
