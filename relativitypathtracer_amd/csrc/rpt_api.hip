@@ -462,7 +462,6 @@ int launch(rpt_ctx *ctx) {
         hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_first_w5, grid, dim3(256), 0, ctx->stream, a);
         break;
     }
-    case 44: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_seg_w5, grid, dim3(256), 0, ctx->stream, a); break;
     case 50:
     case 51:
         if (rpt_launch_relaxed_kernel(v == 51 ? 6 : 5, &a, sizeof a, grid.x, grid.y, (void *)ctx->stream)) return fail(ctx, RPT_ERR_DEVICE, "relaxed-arithmetic kernel launch failed");
@@ -716,7 +715,7 @@ int rpt_object_screen_rect(const void *object, int interval, const float *root_b
 int rpt_set_variant(rpt_ctx *ctx, int variant) {
     if (!ctx) return RPT_ERR_ARG;
     switch (variant) {
-    case 0: case 1: case 3: case 26: case 40: case 41: case 42: case 43: case 44: case 50: case 51: break;
+    case 0: case 1: case 3: case 26: case 40: case 41: case 42: case 43: case 50: case 51: break;
 #ifdef RPT_DIAGNOSTICS
     case 7: case 8: case 11: break;
 #endif

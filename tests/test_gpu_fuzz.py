@@ -38,7 +38,7 @@ def test_random_scene(renderer, seed):
     scene.update_objects()
     W, H = [(320, 184), (256, 144), (200, 150)][seed % 3]
     opx, orgb, _ = oracle_ffi.render(scene, W, H)
-    for variant in (0, 1, 3, 26, 44):                   # default (in-wave ballot cull), reference-layout kernel, unmasked derived-layout kernel, prepass masks
+    for variant in (0, 1, 3, 26):                   # default (in-wave ballot cull), reference-layout kernel, unmasked derived-layout kernel, prepass masks
         renderer.set_variant(variant)
         renderer.upload_scene(scene)
         renderer.set_scene_params(scene, W, H)
