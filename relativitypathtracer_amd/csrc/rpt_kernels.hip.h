@@ -524,45 +524,28 @@ RPT_DEV bool sphere_core(const rpt_object &obj, f3 rayToSphere, float c, f3 dir,
 
 // One object against one ray given as a 4-D event + 4-D direction in the object's rest frame
 // (the general form: shadow rays, and primary rays of the V = 0 kernel).
-// Conservative "certainly apart" test of the segment o + d * [0, tmax] (tmax may be +inf: a ray) against the box [lo, hi],
-// which the caller has already grown by its margin: the slab test with v_rcp_f32 instead of IEEE divisions and no
-// normalisation of d.  A NaN anywhere compares false and keeps the object.  (d = 0 on an axis: the reciprocal is +-inf and the
-// two plane distances become -inf/+inf inside the slab, equal infinities outside it — the right answers; 0 * inf only arises
-// for an origin exactly on a grown plane with no motion across it, where "apart" is true anyway.)
-RPT_DEV bool segment_apart_from_box(f3 o, f3 d, f3 lo, f3 hi, float tmax) {
-    const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
-    const float ax = (lo.x - o.x) * ix, bx = (hi.x - o.x) * ix;
-    const float ay = (lo.y - o.y) * iy, by = (hi.y - o.y) * iy;
-    const float az = (lo.z - o.z) * iz, bz = (hi.z - o.z) * iz;
-    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
-    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), tmax));
-    return tn > tf * 1.001f + 1.0e-4f;
-}
-
 // seg_max > 0 (shadow rays): the caller only asks whether the object is hit at a distance below seg_max (sample_light:
 // dist < lightDist).  A hit at distance s lies at origin + dir * s (dir not yet normalised: hit.dist is measured in its
 // units, opencl_kernel.cl:328,354) ON the object, and a sphere's or a cube's surface lies inside [-1,1]^3: if, for every
-// active lane of the wave, the segment origin + dir * [0, seg_max] is certainly apart from that box (grown by a margin), no
-// lane can get an answer other than "not hit below seg_max", and the normalisation, its three IEEE divisions and the
-// intersector are skipped for the whole wave (__ballot).  For a mesh only the RAY may be used — the reference's walk accepts
-// a triangle where the ray meets its plane, which for another mesh's triangle in a leaf's list (Mesh.cpp:16-19) can be in
-// front of the octree's box — and that is exactly the walk's own first test (intersect_AABB of the root, :218-229), here
-// answered for the whole wave before the normalisation instead of per lane after it.
+// active lane of the wave, the segment origin + dir * [0, seg_max] stays beyond one of that box's six planes (the segment's
+// bounding box against the unit box grown by a margin: three multiply-adds and twelve compares; a NaN compares false and
+// keeps the object), no lane can get an answer other than "not hit below seg_max", and the normalisation, its three IEEE
+// divisions and the intersector are skipped for the whole wave (__ballot).  Meshes are left alone: the reference's walk
+// accepts a triangle where the RAY meets its plane, which for another mesh's triangle in a leaf's list (Mesh.cpp:16-19)
+// can be outside the octree's box, and the ray-against-root-box question is the walk's own first test already.
+// (Measured also: the slab test with v_rcp_f32 as a second stage, and the same for mesh roots as a ray test: no
+// further gain on any scene — three quarter-rate reciprocals cost what they save)
 template <int V>
 RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, Hit &hit, float seg_max = -1.0f) {
     const rpt_object &obj = a.objects[i];
     const f3 origin = transformPoint(obj.InvM, yzw(origin4));
     f3 dir = transformDirection(obj.InvM, yzw(dir4));
-    if (V >= 20 && seg_max > 0.0f) {
-        bool apart;
-        if (obj.type == RPT_MESH) {
-            const DNode &root = a.dnodes[obj.meshIndex];          // wave-uniform: scalar loads
-            const float gx = 0.002f * (root.maxx - root.minx) + 1.0e-5f, gy = 0.002f * (root.maxy - root.miny) + 1.0e-5f, gz = 0.002f * (root.maxz - root.minz) + 1.0e-5f;
-            apart = segment_apart_from_box(origin, dir, mk3(root.minx - gx, root.miny - gy, root.minz - gz),
-                                           mk3(root.maxx + gx, root.maxy + gy, root.maxz + gz), __builtin_inff());
-        } else {
-            apart = segment_apart_from_box(origin, dir, mk3(-1.002f, -1.002f, -1.002f), mk3(1.002f, 1.002f, 1.002f), seg_max * 1.001f + 1.0e-4f);
-        }
+    if (V >= 20 && seg_max > 0.0f && obj.type != RPT_MESH) {
+        const float s = seg_max * 1.001f + 1.0e-4f, m = 1.002f;
+        const f3 e = origin + dir * s;
+        const bool apart = ((origin.x > m) & (e.x > m)) | ((origin.x < -m) & (e.x < -m)) |
+                           ((origin.y > m) & (e.y > m)) | ((origin.y < -m) & (e.y < -m)) |
+                           ((origin.z > m) & (e.z > m)) | ((origin.z < -m) & (e.z < -m));
         if (__ballot(!apart) == 0ull) return false;
     }
     const float scale = length(dir);
