@@ -20,8 +20,10 @@
  *   rpt_render                 runKernel()                          CLSetup.cpp:167-191
  *
  * Not in the reference (it never reads back, has one device and no timing): rpt_read_framebuffer,
- * rpt_last_frame_ms, rpt_timed_frames, the *_async/stream calls, rpt_set_rows (pixel-row tiles for
- * multi-GPU sharding) and rpt_scatter_colour_plane (root-side reassembly after the RCCL gather).
+ * rpt_last_frame_ms, rpt_timed_frames, rpt_timing_*, the *_async/stream calls, rpt_create_multi, rpt_set_rows /
+ * rpt_set_tile_pattern (pixel-row tiles for multi-GPU sharding), rpt_pack_/rpt_scatter_* (the exchange's two kernels),
+ * rpt_build_octree (GPU counterpart of Mesh::GenerateOctree) and the test hooks rpt_probe, rpt_set_debug_rgb,
+ * rpt_object_screen_rect.
  *
  * There is no CPU or OpenCL fallback: without a gfx950 device rpt_create fails.
  */

@@ -603,6 +603,24 @@ def test_frame_sharder_with_virtual_ranks_on_one_gpu(monkeypatch, world, root_ru
                 r.close()
 
 
+def test_create_multi_is_all_or_nothing():
+    """rpt_create_multi: one context per listed device, or none at all."""
+    import ctypes as C
+    from relativitypathtracer_amd import _ffi
+    lib = _ffi.hip()
+    out = (C.c_void_p * 3)()
+    assert lib.rpt_create_multi(out, (C.c_int * 3)(0, 0, 0), 3) == 0 and all(out[k] for k in range(3))
+    scene = load_config("cube")
+    d = scene.desc()
+    assert lib.rpt_upload_scene(out[0], C.byref(d)) == 0
+    assert lib.rpt_share_scene(out[1], out[0]) == 0 and lib.rpt_share_scene(out[2], out[0]) == 0
+    for k in range(3):
+        lib.rpt_destroy(out[k])
+    bad = (C.c_void_p * 2)()
+    assert lib.rpt_create_multi(bad, (C.c_int * 2)(0, 4096), 2) != 0 and not bad[0] and not bad[1]
+    assert lib.rpt_create_multi(bad, (C.c_int * 2)(0, 0), 0) != 0
+
+
 def test_tile_pattern_arguments(renderer):
     """rpt_set_tile_pattern rejects what the kernel's shift/mask tile arithmetic cannot express."""
     from relativitypathtracer_amd.renderer import RenderError
