@@ -603,6 +603,27 @@ def test_frame_sharder_with_virtual_ranks_on_one_gpu(monkeypatch, world, root_ru
                 r.close()
 
 
+def test_cull_records_follow_the_objects_and_the_interval(renderer):
+    """The per-object screen rectangles are cached per object record: a moved camera, a toggled interval (the `i` key,
+    Render.cpp:125-147) and a return to an earlier state must each render exactly the oracle's frame."""
+    scene = load_config("shadows")
+    W, H = 480, 270
+    _setup(renderer, scene, W, H)
+    for v, t, interval in (((0, 0, 0), 16.0, -1), ((0, 0, 0), 16.0, 0), ((0.5, 0.1, 0.3), 9.0, -1), ((0.5, 0.1, 0.3), 9.0, 0),
+                           ((0, 0, 0), 16.0, -1), ((0, 0, 0), 16.0, -1), ((0, 0, -0.9), 2.0, -1)):
+        scene.set_camera(v, t)
+        scene.set_interval(interval)
+        scene.update_objects()
+        renderer.set_scene_params(scene, W, H)
+        renderer.set_objects(scene)
+        renderer.render()
+        opx, _, _ = oracle_ffi.render(scene, W, H, want_rgb=False)
+        assert np.array_equal(renderer.read_framebuffer()["rgba"], opx["rgba"]), (v, t, interval)
+        renderer.render_async()
+        renderer.sync()
+        assert np.array_equal(renderer.read_framebuffer()["rgba"], opx["rgba"]), (v, t, interval, "async")
+
+
 def test_create_multi_is_all_or_nothing():
     """rpt_create_multi: one context per listed device, or none at all."""
     import ctypes as C

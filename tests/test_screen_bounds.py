@@ -121,3 +121,42 @@ def test_rectangles_contain_every_hit_shipped_scenes_random_cameras():
         s.update_objects()
         W, H = [(240, 135), (166, 38), (160, 120)][trial % 3]
         check_scene(s, W, H, f"trial {trial} {name} {W}x{H} v={v} t={t}")
+
+
+ADVERSARIAL = [
+    # huge and tiny scales, a slab seen edge-on, a box the camera stands on, one it is inside of, a sphere it touches
+    "Oc\n p0,0,8,0,0,1,0,1000,1000,0.001\n c1,1,1\nOs\n p0.5,0.2,3,0,0,1,0,0.0001,0.0001,0.0001\n c1,1,1\nA0.5\nR\n",
+    "Oc\n p0,-1.0005,0,0,0,1,0,50,1,50\n c1,1,1\nOc\n p0,0,0,0.7,1,1,0,3,3,3\n c1,0,0\nOs\n p0,0,1.0001,0,0,1,0,1,1,1\n c0,1,0\nA0.5\nR\n",
+    # everything fast: objects at 0.999c in different directions, one receding, one approaching, one passing
+    "Oc\n p0,0,30,0,0,1,0,1,1,1\n c1,1,1\n v0,0,-0.999\nOs\n p3,0,10,0,0,1,0,1,2,1\n c1,1,1\n v0,0,0.999\nOc\n p-40,1,12,0.3,0,1,0,2,1,1\n c1,1,1\n v0.999,0,0\nA0.5\nR\n",
+    # the same with light propagation off (interval 0: the linear, non-aberrated map with boosted objects)
+    "Oc\n p0,0,30,0,0,1,0,1,1,1\n c1,1,1\n v0,0,-0.9\nOs\n p3,0,10,0,0,1,0,1,2,1\n c1,1,1\n v0,0.9,0\nOc\n p-4,1,12,0.3,0,1,0,2,1,1\n c1,1,1\n v0.9,0,0\nA0.5\nI\nR\n",
+    # thin diagonal rulers and a sheared look through rotation + anisotropic scale
+    "Oc\n p0,0,6,0.785,0,0,1,6,0.02,0.02\n c1,1,1\nOc\n p1,1,9,1.1,1,1,1,0.02,7,0.02\n c1,1,1\nA0.5\nR\n",
+]
+
+
+@pytest.mark.parametrize("k", range(len(ADVERSARIAL)))
+def test_rectangles_contain_every_hit_adversarial_objects(k):
+    for v, t in (((0.0, 0.0, 0.0), 0.0), ((0.0, 0.0, 0.99), 3.0), ((0.7, -0.5, 0.3), -2.0), ((-0.3, 0.2, -0.9), 7.5)):
+        s = Scene()
+        s.inputScene(ADVERSARIAL[k])
+        s.set_camera(v, t)
+        s.update_objects()
+        check_scene(s, 240, 136, f"adversarial {k} v={v} t={t}")
+
+
+def test_broken_matrices_keep_the_object():
+    """Non-finite or singular matrices, or an InvLorentz that is not the inverse of Lorentz: no statement is made (full plane)."""
+    s = load_config("shadows")
+    lib = _ffi.hip()
+    objs = s.objects()
+    rect = (C.c_float * 4)()
+    for field, value in (("InvM", np.nan), ("Lorentz", np.inf), ("InvLorentz", 0.0), ("M", 0.0)):
+        o = objs[1:2].copy()
+        o[field][0][1] = value
+        assert lib.rpt_object_screen_rect(o.ctypes.data, -1, None, rect) == 0
+        if field == "M" or field == "InvLorentz":
+            assert rect[0] <= -3e38 and rect[2] >= 3e38 or rect[0] <= rect[2]        # full, or still a valid (checked) rectangle
+        else:
+            assert rect[0] <= -3e38 and rect[1] <= -3e38 and rect[2] >= 3e38 and rect[3] >= 3e38, (field, tuple(rect))
