@@ -127,6 +127,9 @@ int rpt_set_variant(rpt_ctx *ctx, int variant);
  * Lorentz / stationaryCam fields set).  root_bounds: min.xyz, max.xyz of a mesh object's octree root, else NULL.
  * +-3e38 on every side = never culled; u0 > u1 = not visible at all. */
 int rpt_object_screen_rect(const void *object, int interval, const float *root_bounds_or_null, float rect_out[4]);
+/* The whole record: the rectangle, then the diagonal slabs {p_lo, p_hi} on u + v and {m_lo, m_hi} on u - v that cut its
+ * corners where that pays (+-3e38 = no cut); the slabs hold for |u| <= 2, |v| <= 0.55 (frames up to 4 : 1). */
+int rpt_object_screen_bounds(const void *object, int interval, const float *root_bounds_or_null, float bounds_out[8]);
 
 /* Render one frame and wait for it (the reference's runKernel + finish). */
 int rpt_render(rpt_ctx *ctx);

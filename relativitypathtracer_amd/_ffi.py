@@ -132,6 +132,7 @@ HIP_SYMBOLS = {
     "rpt_set_debug_rgb": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rpt_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "rpt_object_screen_rect": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "rpt_object_screen_bounds": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rpt_render": (C.c_int, [C.c_void_p]),
     "rpt_render_async": (C.c_int, [C.c_void_p]),
     "rpt_sync": (C.c_int, [C.c_void_p]),

@@ -399,6 +399,10 @@ int launch(rpt_ctx *ctx) {
     a.aspect = (float)ctx->width / (float)ctx->height;
     a.inv_width = 1.0f / (float)ctx->width;
     a.inv_height = 1.0f / (float)ctx->height;
+    // the diagonal slabs hold inside their window only (rpt_screen_bounds.hpp): frames up to 4 : 1, |v| <= 1/2 always
+    a.diagonals = 0;
+    if (0.5f * a.aspect + 2.0f * a.inv_height * a.aspect <= (float)rptb::DIAG_WINDOW_U && ctx->rects.size() == (size_t)ctx->object_count)
+        for (const rptb::Rect &r : ctx->rects) a.diagonals |= rptb::has_diagonals(r) ? 1 : 0;
     a.object_count = ctx->object_count;
     a.width = ctx->width;
     a.height = ctx->height;
@@ -709,6 +713,14 @@ int rpt_object_screen_rect(const void *object, int interval, const float *root_b
     if (!object || !rect_out) return RPT_ERR_ARG;
     const rptb::Rect r = rptb::object_rect(*(const rpt_object *)object, interval, root_bounds_or_null);
     rect_out[0] = r.u0; rect_out[1] = r.v0; rect_out[2] = r.u1; rect_out[3] = r.v1;
+    return RPT_OK;
+}
+
+int rpt_object_screen_bounds(const void *object, int interval, const float *root_bounds_or_null, float bounds_out[8]) {
+    if (!object || !bounds_out) return RPT_ERR_ARG;
+    const rptb::Rect r = rptb::object_rect(*(const rpt_object *)object, interval, root_bounds_or_null);
+    const float v[8] = {r.u0, r.v0, r.u1, r.v1, r.p_lo, r.p_hi, r.m_lo, r.m_hi};
+    for (int k = 0; k < 8; k++) bounds_out[k] = v[k];
     return RPT_OK;
 }
 

@@ -92,8 +92,10 @@ struct KernelArgs {
     int tiles_x, n_tiles;                    // tiles per row, tiles in this context's rows
     unsigned long long *tile_masks;          // [n_tiles] bit i = primary rays of the tile may hit object i (i < 64)
     // per-object image-plane rectangles (rpt_screen_bounds.hpp), tested lane-parallel by each wavefront (V >= 20)
-    const float4 *rects;                     // [object_count] u0, v0, u1, v1 on the plane z = 0.5
+    const float4 *rects;                     // [2 * object_count] per object: u0, v0, u1, v1 on the plane z = 0.5, then the
+                                             // diagonal slabs p_lo, p_hi (u + v) and m_lo, m_hi (u - v)
     float inv_width, inv_height;             // 1/width, 1/height (for the cull only: approximate is fine there)
+    int diagonals;                           // some object has diagonal slabs and the frame lies inside their window
     // dispatch order (V == 23): the strips [first_sx, first_sx + first_w) x [first_ty, first_ty + first_h) — where the meshes
     // are, i.e. where the frame's longest waves live — are handed out FIRST, the rest in natural order; first_w = 0: off
     int first_sx, first_ty, first_w, first_h;
@@ -754,7 +756,8 @@ RPT_DEV uint32_t tonemap_pack(const KernelArgs &a, f3 color, f3 &mapped) {
 }
 
 // The wavefront's object mask, computed by the wavefront itself: lane i compares the image-plane rectangle of object i
-// (rpt_screen_bounds.hpp: outside it no primary ray reaches the object) with the wave's 8x8-pixel tile, grown by a pixel
+// (rpt_screen_bounds.hpp: outside it no primary ray reaches the object; where it pays, an octagon: the rectangle with
+// corners cut by two diagonal slabs) with the wave's 8x8-pixel tile, grown by a pixel
 // and a half on every side, and one __ballot makes the 64 answers the mask — in SGPRs, wave-uniform, with no prepass
 // kernel, no mask buffer and no dependent load behind it.  Pixel (x, y) looks through the plane point
 // ((x/W - 0.5) * aspect, y/H - 0.5) (opencl_kernel.cl:57-63).  NaNs compare false, so a broken rectangle keeps its object.
@@ -763,11 +766,16 @@ RPT_DEV unsigned long long wave_object_mask(const KernelArgs &a, int tile_x0, in
     // one 16-B load per lane, issued unconditionally (lanes beyond the object count re-read rectangle 0: always a valid
     // address when there is any object), and four compares without branches: one memory round trip, no divergence
     const int n = a.object_count;
-    const float4 r = a.rects[(lane < n) ? lane : 0];
+    const int slot = (lane < n) ? lane : 0;
+    const float4 r = a.rects[2 * slot];
     const float iw = a.inv_width, ih = a.inv_height;
     const float tu0 = (((float)tile_x0 - 1.5f) * iw - 0.5f) * a.aspect, tu1 = (((float)tile_x0 + 8.5f) * iw - 0.5f) * a.aspect;
     const float tv0 = ((float)tile_y0 - 1.5f) * ih - 0.5f, tv1 = ((float)tile_y0 + 8.5f) * ih - 0.5f;
-    const bool outside = (r.z < tu0) | (r.x > tu1) | (r.w < tv0) | (r.y > tv1);
+    bool outside = (r.z < tu0) | (r.x > tu1) | (r.w < tv0) | (r.y > tv1);
+    if (a.diagonals) {      // wave-uniform: the octagon's four diagonal sides (u + v and u - v over the tile's corners)
+        const float4 g = a.rects[2 * slot + 1];
+        outside = outside | (g.y < tu0 + tv0) | (g.x > tu1 + tv1) | (g.w < tu0 - tv1) | (g.z > tu1 - tv0);
+    }
     const bool keep = (lane < n) & !outside;
     return __ballot(keep);
 }

@@ -28,10 +28,17 @@
 
 namespace rptb {
 
-struct Rect { float u0, v0, u1, v1; };      // keep the object for a tile iff the tile's plane rectangle overlaps this one
+// Keep the object for a tile iff the tile's plane rectangle overlaps [u0,u1] x [v0,v1] AND reaches into the two diagonal
+// slabs p_lo <= u + v <= p_hi, m_lo <= u - v <= m_hi (an octagon: the rectangle with its corners cut where that pays —
+// a floor's horizon bent into a V by aberration, a ruler lying diagonally).  The diagonal bounds hold for the part of the
+// region inside the window |u| <= DIAG_WINDOW_U, |v| <= DIAG_WINDOW_V only (they are taken from the outline clipped to it,
+// so that what an outline does on its way to the horizon cannot spoil them): the kernel uses them for frames that fit it.
+struct Rect { float u0, v0, u1, v1, p_lo, p_hi, m_lo, m_hi; };
+constexpr double DIAG_WINDOW_U = 2.0, DIAG_WINDOW_V = 0.55;      // frames up to 4 : 1
 
-inline Rect full_rect() { return Rect{-3.0e38f, -3.0e38f, 3.0e38f, 3.0e38f}; }
-inline Rect empty_rect() { return Rect{3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f}; }
+inline Rect full_rect() { return Rect{-3.0e38f, -3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f}; }
+inline Rect empty_rect() { return Rect{3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f}; }
+inline bool has_diagonals(const Rect &r) { return r.p_lo > -3.0e38f || r.p_hi < 3.0e38f || r.m_lo > -3.0e38f || r.m_hi < 3.0e38f; }
 
 namespace detail {
 
@@ -134,35 +141,73 @@ inline DirMap make_map(const rpt_object &o, int interval) {
 // Accumulates the image-plane bounding box of a sampled closed or open curve of object-space directions.
 struct Accum {
     const DirMap &m;
-    Accum &operator=(const Accum &o) { u0 = o.u0; v0 = o.v0; u1 = o.u1; v1 = o.v1; failed = o.failed; any_front = o.any_front; any_near_behind = o.any_near_behind; n_crossings = o.n_crossings; return *this; }
+    Accum &operator=(const Accum &o) {
+        u0 = o.u0; v0 = o.v0; u1 = o.u1; v1 = o.v1; failed = o.failed; any_front = o.any_front; any_near_behind = o.any_near_behind;
+        n_crossings = o.n_crossings; p_lo = o.p_lo; p_hi = o.p_hi; m_lo = o.m_lo; m_hi = o.m_hi; pen = o.pen; pen_u = o.pen_u; pen_v = o.pen_v;
+        return *this;
+    }
     double u0 = 1e300, v0 = 1e300, u1 = -1e300, v1 = -1e300;
+    // extents of u + v and u - v over the outline clipped to the diagonal window; the outline is fed as polylines
+    double p_lo = 1e300, p_hi = -1e300, m_lo = 1e300, m_hi = -1e300;
+    bool pen = false;
+    double pen_u = 0.0, pen_v = 0.0;
+    void diag_point(double u, double v) {
+        p_lo = std::min(p_lo, u + v); p_hi = std::max(p_hi, u + v); m_lo = std::min(m_lo, u - v); m_hi = std::max(m_hi, u - v);
+    }
+    void diag_segment(double ua, double va, double ub, double vb) {      // Liang-Barsky clip to the window, then both end points
+        double t0 = 0.0, t1 = 1.0;
+        const double du = ub - ua, dv = vb - va;
+        const double pp[4] = {-du, du, -dv, dv}, qq[4] = {ua + DIAG_WINDOW_U, DIAG_WINDOW_U - ua, va + DIAG_WINDOW_V, DIAG_WINDOW_V - va};
+        for (int k = 0; k < 4; k++) {
+            if (pp[k] == 0.0) { if (qq[k] < 0.0) return; continue; }
+            const double r = qq[k] / pp[k];
+            if (pp[k] < 0.0) { if (r > t1) return; t0 = std::max(t0, r); }
+            else { if (r < t0) return; t1 = std::min(t1, r); }
+        }
+        if (!(t0 <= t1)) return;
+        diag_point(ua + du * t0, va + dv * t0);
+        diag_point(ua + du * t1, va + dv * t1);
+    }
+    void pen_up() { pen = false; }
+    // the next point of the current polyline (a direction in front of the camera): box, and the segment from the last one
+    void point(D3 nd) {
+        const double u = 0.5 * nd.x / nd.z, v = 0.5 * nd.y / nd.z;
+        u0 = std::min(u0, u); u1 = std::max(u1, u); v0 = std::min(v0, v); v1 = std::max(v1, v);
+        if (pen) diag_segment(pen_u, pen_v, u, v);
+        else diag_segment(u, v, u, v);
+        pen = true; pen_u = u; pen_v = v;
+        any_front = true;
+    }
     bool failed = false, any_front = false, any_near_behind = false;
     int n_crossings = 0;
     explicit Accum(const DirMap &map) : m(map) {}
 
     static double frontness(D3 nd) { return nd.z - EPS_FRONT * len(nd); }
-    void take(D3 nd) {      // a direction in front of the camera
+    void take(D3 nd) {      // a lone direction in front of the camera (horizon samples: far outside the diagonal window)
         const double u = 0.5 * nd.x / nd.z, v = 0.5 * nd.y / nd.z;
         u0 = std::min(u0, u); u1 = std::max(u1, u); v0 = std::min(v0, v); v1 = std::max(v1, v);
     }
-    // one sample; returns its camera direction in nd (valid unless failed).  `verify`: push it through F again
-    // (done at the end points of every edge and at every fourth sample of a circle; a wrong inverse shows there too)
-    bool sample(D3 u_obj, D3 &nd, bool &front, bool verify = true) {
+    // Map one sample of the outline: its camera direction in nd and whether that is in front of the camera; nothing is
+    // recorded yet (the caller feeds crossings and points in curve order).  `verify`: push it through F again (done at
+    // the end points of every edge and at every eighth sample of a rim; a wrong inverse shows there too).
+    bool map_sample(D3 u_obj, D3 &nd, bool &front, bool verify) {
         if (!(verify ? m.G_checked(u_obj, nd) : m.G(u_obj, nd))) { failed = true; return false; }
-        front = frontness(nd) > 0.0;
-        if (front) { take(nd); any_front = true; }
-        else if (nd.z > -0.2 * len(nd)) any_near_behind = true;
+        classify(nd, front);
         return true;
     }
-    void take_mapped(D3 nd, bool &front) {     // a sample whose camera direction is already known
+    void classify(D3 nd, bool &front) {
         front = frontness(nd) > 0.0;
-        if (front) { take(nd); any_front = true; }
-        else if (nd.z > -0.2 * len(nd)) any_near_behind = true;
+        if (!front && nd.z > -0.2 * len(nd)) any_near_behind = true;
+    }
+    // one more sample of the polyline being drawn, after map_sample/classify (and crossing(), if the side changed)
+    void feed(D3 nd, bool front) {
+        if (front) point(nd);
+        else pen_up();
     }
     // the curve between two consecutive samples crosses the clip cone: locate the crossing by bisection on the
     // object-space segment between them (exact for straight edges, close enough for arcs: the margin covers it)
     void crossing(D3 ua, D3 ub, bool front_a) {
-        D3 lo = ua, hi = ub;      // lo on the front side when front_a, else hi
+        D3 lo = ua, hi = ub;      // lo keeps ua's side, hi ub's
         for (int it = 0; it < 18; it++) {
             const D3 mid = mul(add(lo, hi), 0.5);
             D3 nd;
@@ -170,22 +215,31 @@ struct Accum {
             const bool f = frontness(nd) > 0.0;
             if (f == front_a) lo = mid; else hi = mid;
         }
-        D3 nd;
-        if (!m.G_checked(front_a ? lo : hi, nd) || !(nd.z > 0.0)) { failed = true; return; }
-        take(nd);
-        any_front = true;
+        const D3 cross_u = front_a ? lo : hi, from_u = front_a ? ua : ub;      // the front side of the crossing; the front sample
+        D3 xnd;
+        if (!m.G_checked(cross_u, xnd) || !(xnd.z > 0.0)) { failed = true; return; }
         n_crossings++;
+        // A curved outline runs off towards the horizon along an asymptote and may swing past both of its end points on the
+        // way: it is followed between the sample in front and the crossing in steps that halve the distance to the crossing.
+        D3 way[10];
+        int n_way = 0;
         if (!m.linear) {
-            // a curved outline runs off towards the horizon along an asymptote and may swing past both of its end points on
-            // the way: follow it from the last sample in front (ua or ub) to the crossing in steps that halve the distance
-            const D3 cross_u = front_a ? lo : hi, from_u = front_a ? ua : ub;
             double w = 0.5;
             for (int k = 0; k < 10; k++, w *= 0.5) {
                 const D3 u = add(mul(cross_u, 1.0 - w), mul(from_u, w));
                 D3 n2;
                 if (!m.G(u, n2)) { failed = true; return; }
-                if (frontness(n2) > 0.0) take(n2);
+                if (frontness(n2) > 0.0) way[n_way++] = n2;
             }
+        }
+        if (front_a) {              // the pen stands on the front sample: ... -> way[0] -> ... -> crossing, and up
+            for (int k = 0; k < n_way; k++) point(way[k]);
+            point(xnd);
+            pen_up();
+        } else {                    // a new stretch starts at the crossing and runs towards the front sample the caller adds next
+            pen_up();
+            point(xnd);
+            for (int k = n_way - 1; k >= 0; k--) point(way[k]);
         }
     }
     // The horizon circle nd.z = EPS |nd|: which part of it lies inside the kept region?  `inside(d)` answers for an
@@ -210,20 +264,46 @@ struct Accum {
         }
         return count;
     }
+    // The diagonal extents are those of (region ∩ window): besides the outline clipped to the window, that set's boundary
+    // can run along the window's own edges, where u + v and u - v are monotone — so it ends in a window corner (asked here)
+    // or where the outline crosses the edge (already taken with the clipped outline).
+    template <class Inside>
+    void window_corners(Inside inside) {
+        for (int k = 0; k < 4; k++) {
+            const double u = (k & 1) ? DIAG_WINDOW_U : -DIAG_WINDOW_U, v = (k & 2) ? DIAG_WINDOW_V : -DIAG_WINDOW_V;
+            if (inside(m.F(D3{2.0 * u, 2.0 * v, 1.0}))) diag_point(u, v);
+        }
+    }
 };
 
 inline Rect finish(const Accum &acc, double rel_margin) {
     if (acc.failed) return full_rect();
     if (!acc.any_front) return acc.any_near_behind ? full_rect() : empty_rect();      // wholly (and well) behind the camera
     // margins relative to the part of the box that can matter (screens reach |u| <= aspect/2, |v| <= 1/2; clipped curves
-    // reach out to |u|, |v| ~ 25, which must not loosen the sides that lie on the screen)
-    auto cl = [](double x) { return std::max(-1.5, std::min(1.5, x)); };
-    const double mu = rel_margin * (cl(acc.u1) - cl(acc.u0)) + 1.0e-3, mv = rel_margin * (cl(acc.v1) - cl(acc.v0)) + 1.0e-3;
+    // reach out to |u|, |v| ~ 25, which must not loosen the sides that lie on the screen; wider screens than 2.5 : 1 only
+    // get a margin that is smaller relative to their width, and the 1e-3 floor)
+    auto clu = [](double x) { return std::max(-1.25, std::min(1.25, x)); };     // screens up to 2.5 : 1
+    auto clv = [](double x) { return std::max(-0.55, std::min(0.55, x)); };
+    const double mu = rel_margin * (clu(acc.u1) - clu(acc.u0)) + 1.0e-3, mv = rel_margin * (clv(acc.v1) - clv(acc.v0)) + 1.0e-3;
     const double r[4] = {acc.u0 - mu, acc.v0 - mv, acc.u1 + mu, acc.v1 + mv};
     for (double x : r) if (!std::isfinite(x)) return full_rect();
     auto clampf = [](double x) { return (float)std::max(-3.0e38, std::min(3.0e38, x)); };
     // round outwards
-    Rect out{std::nextafter(clampf(r[0]), -INFINITY), std::nextafter(clampf(r[1]), -INFINITY), std::nextafter(clampf(r[2]), INFINITY), std::nextafter(clampf(r[3]), INFINITY)};
+    Rect out = full_rect();
+    out.u0 = std::nextafter(clampf(r[0]), -INFINITY); out.v0 = std::nextafter(clampf(r[1]), -INFINITY);
+    out.u1 = std::nextafter(clampf(r[2]), INFINITY); out.v1 = std::nextafter(clampf(r[3]), INFINITY);
+    // The diagonal slabs, if they cut enough off the box to pay for their test: a corner cut of size c (in u + v or u - v)
+    // removes a triangle of area c^2 / 2 from the on-screen box; at least a tenth of it must go.
+    if (acc.p_lo <= acc.p_hi) {
+        const double U0 = clu(r[0]), U1 = clu(r[2]), V0 = clv(r[1]), V1 = clv(r[3]), md = mu + mv;
+        const double plo = acc.p_lo - md, phi = acc.p_hi + md, mlo = acc.m_lo - md, mhi = acc.m_hi + md;
+        auto sq = [](double c) { return c > 0.0 ? 0.5 * c * c : 0.0; };
+        const double cut = sq((U1 + V1) - phi) + sq(plo - (U0 + V0)) + sq((U1 - V0) - mhi) + sq(mlo - (U0 - V1));
+        if (cut >= 0.1 * (U1 - U0) * (V1 - V0) && std::isfinite(plo) && std::isfinite(phi) && std::isfinite(mlo) && std::isfinite(mhi)) {
+            out.p_lo = std::nextafter((float)plo, -INFINITY); out.p_hi = std::nextafter((float)phi, INFINITY);
+            out.m_lo = std::nextafter((float)mlo, -INFINITY); out.m_hi = std::nextafter((float)mhi, INFINITY);
+        }
+    }
     return out;
 }
 
@@ -304,10 +384,13 @@ resample:
                 const D3 u = j == 0 ? cu[k_lo] : (j == S ? cu[k_hi] : sub(D3{q[0], q[1], q[2]}, oc));
                 D3 nd;
                 bool front = false;
-                if (j == 0 || j == S) acc.take_mapped(nd = (j == 0 ? cnd[k_lo] : cnd[k_hi]), front);
-                else if (!acc.sample(u, nd, front, false)) break;
+                if (j == 0 || j == S) acc.classify(nd = (j == 0 ? cnd[k_lo] : cnd[k_hi]), front);
+                else if (!acc.map_sample(u, nd, front, false)) break;
                 clipped = clipped || !front;
-                if (j > 0 && front != prev_front) acc.crossing(prev_u, u, prev_front);
+                if (j == 0) acc.pen_up();                       // every edge is a polyline of its own
+                else if (front != prev_front) acc.crossing(prev_u, u, prev_front);
+                if (acc.failed) break;
+                acc.feed(nd, front);
                 prev_u = u; prev_front = front;
             }
         }
@@ -328,6 +411,7 @@ resample:
     } else {
         acc.horizon(32, inside_box);
     }
+    acc.window_corners(inside_box);
     return finish(acc, m.linear ? 0.002 : 0.025);
 }
 
@@ -352,20 +436,25 @@ inline Rect sphere_rect(const rpt_object &o, int interval) {
     const int K = m.linear ? 16 : 32;      // samples on the tangent cone's rim
     Accum acc(m);
     bool clipped = false;
-    D3 first_u{}, prev_u{};
+    D3 first_u{}, prev_u{}, first_nd{};
     bool first_front = false, prev_front = false;
     for (int k = 0; k < K && !acc.failed; k++) {
         const double phi = 2.0 * M_PI * k / K;
         const D3 u = add(mul(axis, ca), mul(add(mul(e1, std::cos(phi)), mul(e2, std::sin(phi))), sa));
         D3 nd;
         bool front = false;
-        if (!acc.sample(u, nd, front, (k & 7) == 0)) break;
+        if (!acc.map_sample(u, nd, front, (k & 7) == 0)) break;
         clipped = clipped || !front;
-        if (k == 0) { first_u = u; first_front = front; }
+        if (k == 0) { first_u = u; first_front = front; first_nd = nd; }
         else if (front != prev_front) acc.crossing(prev_u, u, prev_front);
+        if (acc.failed) break;
+        acc.feed(nd, front);
         prev_u = u; prev_front = front;
     }
-    if (!acc.failed && prev_front != first_front) acc.crossing(prev_u, first_u, prev_front);
+    if (!acc.failed) {                                          // close the rim
+        if (prev_front != first_front) acc.crossing(prev_u, first_u, prev_front);
+        if (!acc.failed) acc.feed(first_nd, first_front);
+    }
     if (acc.failed) return full_rect();
     const double cos_in = std::cos(std::min(1.5, std::asin(sa) * 1.05 + 0.01));      // the cone, a little wider
     auto inside_cone = [&](D3 d) {
@@ -377,6 +466,7 @@ inline Rect sphere_rect(const rpt_object &o, int interval) {
     } else {
         acc.horizon(32, inside_cone);
     }
+    acc.window_corners(inside_cone);
     return finish(acc, 0.04);
 }
 

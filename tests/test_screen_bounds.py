@@ -26,10 +26,19 @@ def object_rects(scene):
         if int(objs["type"][i]) == 2:
             n = nodes[int(objs["meshIndex"][i])]
             root = (C.c_float * 6)(*n["min"][:3], *n["max"][:3])
-        rect = (C.c_float * 4)()
-        assert lib.rpt_object_screen_rect(raw.ctypes.data, scene.params["interval"], root, rect) == 0
+        rect = (C.c_float * 8)()
+        assert lib.rpt_object_screen_bounds(raw.ctypes.data, scene.params["interval"], root, rect) == 0
         out.append(tuple(rect))
     return out
+
+
+def inside_bounds(b, u, v):
+    """The kernel's acceptance region: the rectangle and — for frames inside the slabs' window, |u| <= 2 (launch() in
+    csrc/rpt_api.hip switches them off for wider ones) — the two diagonal slabs."""
+    ok = (u >= b[0]) & (u <= b[2]) & (v >= b[1]) & (v <= b[3])
+    if float(np.abs(u).max()) > 2.0:
+        return ok
+    return ok & (u + v >= b[4]) & (u + v <= b[5]) & (u - v >= b[6]) & (u - v <= b[7])
 
 
 def hit_mask(scene, i, W, H):
@@ -61,11 +70,11 @@ def check_scene(scene, W, H, label):
     u = (xs / W - 0.5) * (W / H)
     v = ys / H - 0.5
     culled_something = False
-    for i, (u0, v0, u1, v1) in enumerate(rects):
+    for i, b in enumerate(rects):
         hit = hit_mask(scene, i, W, H)
-        inside = (u >= u0) & (u <= u1) & (v >= v0) & (v <= v1)
+        inside = inside_bounds(b, u, v)
         bad = hit & ~inside
-        assert not bad.any(), f"{label}: object {i}: {int(bad.sum())} hit pixels outside its rectangle {(u0, v0, u1, v1)}"
+        assert not bad.any(), f"{label}: object {i}: {int(bad.sum())} hit pixels outside its bounds {b}"
         culled_something = culled_something or not inside.all()
     return culled_something
 
@@ -88,7 +97,7 @@ def test_rectangles_are_tight_on_the_benchmark_scenes():
         W, H = 320, 180
         ys, xs = np.mgrid[0:H, 0:W]
         u, v = (xs / W - 0.5) * (W / H), ys / H - 0.5
-        kept = [((u >= r[0]) & (u <= r[2]) & (v >= r[1]) & (v <= r[3])).mean() for r in object_rects(scene)]
+        kept = [inside_bounds(r, u, v).mean() for r in object_rects(scene)]
         assert 1.0 - float(np.mean(kept)) >= min_culled_fraction, (name, kept)
 
 
