@@ -306,6 +306,7 @@ void build_rects(rpt_ctx *ctx, const rpt_object *objs, int count, rptb::Rect *ou
     ctx->rects.resize((size_t)count);
     for (int i = 0; i < count; i++) {
         const rpt_object &o = objs[i];
+        if (i >= 64) { out[i] = ctx->rects[i] = rptb::full_rect(); continue; }      // the wave's mask has 64 bits: later objects are always tested
         if (prev && std::memcmp(&prev[i], &o, sizeof o) == 0) { out[i] = ctx->rects[i]; continue; }
         const float *root = nullptr;
         if (o.type == RPT_MESH && o.meshIndex >= 0 && (size_t)o.meshIndex * 6 + 5 < ctx->geo->host_node_bounds.size())

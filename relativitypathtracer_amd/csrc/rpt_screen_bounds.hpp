@@ -267,6 +267,8 @@ struct Accum {
     // The diagonal extents are those of (region ∩ window): besides the outline clipped to the window, that set's boundary
     // can run along the window's own edges, where u + v and u - v are monotone — so it ends in a window corner (asked here)
     // or where the outline crosses the edge (already taken with the clipped outline).
+    // (a region whose box lies strictly inside the window contains none of its corners)
+    bool reaches_window_edge() const { return !(u0 > -DIAG_WINDOW_U && u1 < DIAG_WINDOW_U && v0 > -DIAG_WINDOW_V && v1 < DIAG_WINDOW_V); }
     template <class Inside>
     void window_corners(Inside inside) {
         for (int k = 0; k < 4; k++) {
@@ -408,11 +410,13 @@ resample:
     for (int a = 0; a < 3; a++) { const double g = 0.05 * (hi[a] - lo[a]) + 1.0e-4; blo[a] = lo[a] - g; bhi[a] = hi[a] + g; }
     auto inside_box = [&](D3 d) { return !finite3(d) || ray_meets_box(p, d, blo, bhi); };
     if (!clipped) {
-        if (acc.horizon(8, inside_box) > 0) acc.horizon(32, inside_box);
+        // (a linear map keeps the cone of kept directions convex: with its whole outline in front of the camera it cannot
+        // reach the horizon, so only aberrated outlines are asked)
+        if (!m.linear && acc.horizon(8, inside_box) > 0) acc.horizon(32, inside_box);
     } else {
         acc.horizon(32, inside_box);
     }
-    acc.window_corners(inside_box);
+    if (acc.reaches_window_edge()) acc.window_corners(inside_box);
     return finish(acc, m.linear ? 0.002 : 0.025);
 }
 
@@ -463,11 +467,11 @@ inline Rect sphere_rect(const rpt_object &o, int interval) {
         return !finite3(d) || !(l > 0.0) || dot(d, axis) >= cos_in * l;
     };
     if (!clipped) {
-        if (acc.horizon(8, inside_cone) > 0) acc.horizon(32, inside_cone);
+        if (!m.linear && acc.horizon(8, inside_cone) > 0) acc.horizon(32, inside_cone);
     } else {
         acc.horizon(32, inside_cone);
     }
-    acc.window_corners(inside_cone);
+    if (acc.reaches_window_edge()) acc.window_corners(inside_cone);
     return finish(acc, 0.04);
 }
 
