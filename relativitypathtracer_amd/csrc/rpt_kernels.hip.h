@@ -10,7 +10,10 @@
 //     not depend on the pixel (aspect ratio, hable(white_point)) are computed once on the host
 //     with the same IEEE operations;
 //   * 16 B/pixel framebuffer stores are one global_store_dwordx4 per lane; the multi-GPU variant
-//     writes only the 4-B packed colour into a compact plane.
+//     writes only the 4-B packed colour into a compact plane;
+//   * what a wavefront can skip as a whole it skips with a __ballot: its object mask for the primary rays comes from
+//     per-object screen bounds (host, rpt_screen_bounds.hpp) tested lane-parallel (wave_object_mask), and a shadow ray's
+//     sphere and cube tests are dropped when no lane's segment to the light can reach the object's box (intersect_object).
 // fp32 arithmetic order is that of the reference expression by expression (see the oracle for the
 // built-in semantics); UB of the reference is neutralised exactly as in oracle/rpt_oracle.c.
 #pragma once
@@ -298,19 +301,6 @@ RPT_DEV bool intersect_triangle_edges(f3 A, f3 v0v1, f3 v0v2, const Ray &ray, fl
     if (uv.y < 0 || uv.x + uv.y > 1) return false;
     dist = dot(v0v2, qvec) * invDet;
     return true;
-}
-
-struct DTriRec { f3 A, v0v1, v0v2; int id; };
-
-RPT_DEV DTriRec load_dtri(const KernelArgs &a, int k) {
-    const v4f *p = reinterpret_cast<const v4f *>(a.dtris + k);
-    const v4f t0 = p[0], t1 = p[1], t2 = p[2];
-    DTriRec r;
-    r.A = mk3(t0.x, t0.y, t0.z);
-    r.v0v1 = mk3(t0.w, t1.x, t1.y);
-    r.v0v2 = mk3(t1.z, t1.w, t2.x);
-    r.id = __float_as_int(t2.y);
-    return r;
 }
 
 // opencl_kernel.cl:200-308 from the point where the ray is in object space.  newRay = object-space
