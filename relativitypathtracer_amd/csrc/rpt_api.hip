@@ -112,7 +112,7 @@ int fail(rpt_ctx *ctx, int code, const std::string &msg) {
     } while (0)
 
 int reserve(rpt_ctx *ctx, DeviceBuffer &b, size_t bytes) {
-    if (bytes > b.capacity) {
+    if (bytes > b.capacity || !b.ptr) {      // (!ptr: an empty array still gets a valid, never dereferenced, pointer)
         if (b.ptr) RPT_HIP(ctx, hipFree(b.ptr));
         b.ptr = nullptr;
         b.capacity = 0;

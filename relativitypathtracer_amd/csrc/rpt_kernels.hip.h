@@ -756,6 +756,7 @@ RPT_DEV unsigned long long wave_object_mask(const KernelArgs &a, int tile_x0, in
     // one 16-B load per lane, issued unconditionally (lanes beyond the object count re-read rectangle 0: always a valid
     // address when there is any object), and four compares without branches: one memory round trip, no divergence
     const int n = a.object_count;
+    if (n <= 0) return 0ull;                // a scene without objects has no records to read (wave-uniform)
     const int slot = (lane < n) ? lane : 0;
     const float4 r = a.rects[2 * slot];
     const float iw = a.inv_width, ih = a.inv_height;

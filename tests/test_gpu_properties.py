@@ -624,6 +624,25 @@ def test_cull_records_follow_the_objects_and_the_interval(renderer):
         assert np.array_equal(renderer.read_framebuffer()["rgba"], opx["rgba"]), (v, t, interval, "async")
 
 
+def test_scene_without_objects(renderer):
+    """Zero-length arrays are legal at the boundary (main.cpp:34 passes NULL for empty vectors): a scene with no objects
+    renders the background everywhere, on every kernel variant, blocking and asynchronous."""
+    from relativitypathtracer_amd import Scene
+    s = Scene()
+    s.inputScene("A0.2\nR\n")
+    s.update_objects()
+    W, H = 333, 77
+    opx, _, _ = oracle_ffi.render(s, W, H, want_rgb=False)
+    for variant in (0, 1, 3, 26, 41, 43):
+        _setup(renderer, s, W, H, variant)
+        renderer.render()
+        assert np.array_equal(renderer.read_framebuffer()["rgba"], opx["rgba"]), variant
+        renderer.render_async()
+        renderer.sync()
+        assert np.array_equal(renderer.read_framebuffer()["rgba"], opx["rgba"]), variant
+    _setup(renderer, s, W, H, 0)
+
+
 def test_create_multi_is_all_or_nothing():
     """rpt_create_multi: one context per listed device, or none at all."""
     import ctypes as C
