@@ -643,6 +643,38 @@ def test_scene_without_objects(renderer):
     _setup(renderer, s, W, H, 0)
 
 
+@pytest.mark.parametrize("n_objects", [63, 64, 65, 100])
+def test_more_objects_than_mask_bits(renderer, n_objects):
+    """The wave's object mask has 64 bits: objects 0..63 are culled per tile, later ones are always tested.  A grid of small
+    cubes and spheres (some lights, some moving) around that limit, camera at rest and moving, every masked variant."""
+    from relativitypathtracer_amd import Scene
+    rng = np.random.default_rng(n_objects)
+    lines = []
+    for k in range(n_objects):
+        x, y, z = (k % 10 - 4.5) * 1.4, ((k // 10) % 10 - 4.5) * 0.9, 14.0 + 0.37 * (k % 7)
+        lines.append("Oc" if k % 3 else "Os")
+        lines.append(f" p{x:.3f},{y:.3f},{z:.3f},{0.3 * (k % 5):.2f},1,{k % 2},0,0.6,0.45,0.5")
+        lines.append(" c" + ",".join(f"{v:.2f}" for v in rng.uniform(0.2, 1.0, size=3)))
+        if k in (5, 70):
+            lines.append(" l1")
+        if k % 11 == 0:
+            lines.append(" v0.4,0,0.2")
+    text = "\n".join(lines) + "\nA0.3\nR\n"
+    W, H = 320, 184
+    for v, t in (((0, 0, 0), 2.0), ((0.2, -0.1, 0.6), 4.0)):
+        s = Scene()
+        s.inputScene(text)
+        s.set_camera(v, t)
+        s.update_objects()
+        opx, _, _ = oracle_ffi.render(s, W, H, want_rgb=False)
+        assert (opx["rgba"][:, :3] != opx["rgba"][0, :3]).any(axis=1).mean() > 0.03      # the grid is on screen
+        for variant in (0, 3, 26, 41, 43):
+            _setup(renderer, s, W, H, variant)
+            renderer.render()
+            assert np.array_equal(renderer.read_framebuffer()["rgba"], opx["rgba"]), (n_objects, v, variant)
+    _setup(renderer, s, W, H, 0)
+
+
 def test_create_multi_is_all_or_nothing():
     """rpt_create_multi: one context per listed device, or none at all."""
     import ctypes as C
