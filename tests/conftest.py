@@ -68,7 +68,10 @@ SHADOWS_PEAR_OBJECT = 4                   # index of the mesh object in Scenes/s
 REFERENCE_GIF_FRAMES = {
     "cubes": [("cubes", 26, 5.85)],                                                        # light propagation on
     "ladder": [("ladder_paradox", 60, 2.42), ("ladder_paradox", 100, 3.98), ("ladder_paradox", 140, 5.56)],   # off
+    # the same scene from the ladder's frame: camera at tanh(7361/5000) c = 0.9c along x, light propagation off
+    "ladderframe": [("ladder_paradox", 60, 3.075), ("ladder_paradox", 100, 4.65), ("ladder_paradox", 140, 6.225)],
 }
+LADDER_FRAME_CAMERA_V = (math.tanh(7361 / 5000.0), 0.0, 0.0)
 CLIENT_W, CLIENT_H = 2560, 1377      # client area of the reference's 2560x1400 window grabs
 
 

@@ -21,6 +21,11 @@ bar; the client area is 2560x1377.
                          pin the geometry of MOVING OBJECTS to the resolution of a rescaled palette image; their clock
                          values (tests/conftest.py::REFERENCE_GIF_FRAMES) were found like the grabs' — and come out
                          40 ms per frame apart for the ladder, the GIF's own frame time.
+  ladder_paradox_ladder_frame.gif
+                         the same scene from a camera moving WITH the ladder (0.9c, light propagation off): a moving camera and
+                         moving objects together, the door slanted by the relativity of simultaneity.  Velocity tanh(7361/5000) c
+                         (the rapidity step nearest 0.9c), clocks 3.075 / 4.65 / 6.225 s for frames 60 / 100 / 140: 39.4 ms apart
+                         per GIF frame again.
 
   shadows1/2/4/5.png     Scenes/shadows.txt (README.md:117-122) from a camera at rest with light propagation on: a light
                          sphere crossing the scene at 0.95c, two cubes, a sphere and the pear MESH (Models/pear.obj through
@@ -67,9 +72,10 @@ for name, crop in CROPS.items():
     if crop:
         y0, y1, x0, x1 = crop
         Image.fromarray(np.ascontiguousarray(im[y0:y1, x0:x1])).save(os.path.join(DST, f"ref_{name}_crop_y{y0}_x{x0}.png"), optimize=True)
-for gif, frames in (("cubes", (26,)), ("ladder_paradox_garage_frame", (60, 100, 140))):
+for gif, frames, stem in (("cubes", (26,), "cubes"), ("ladder_paradox_garage_frame", (60, 100, 140), "ladder"),
+                         ("ladder_paradox_ladder_frame", (60, 100, 140), "ladderframe")):
     im = Image.open(os.path.join(SRC, gif + ".gif"))
     for f in frames:
         im.seek(f)
-        im.convert("RGB").save(os.path.join(DST, f"ref_{gif.split('_')[0]}_gif_frame{f}.png"), optimize=True)
+        im.convert("RGB").save(os.path.join(DST, f"ref_{stem}_gif_frame{f}.png"), optimize=True)
 print("ok")

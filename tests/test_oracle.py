@@ -160,9 +160,9 @@ def test_reference_screenshot_shadows_mesh_path(shot, budget):
     assert off_pixels(-0.003) > 3 * here + 20 and off_pixels(0.003) > 3 * here + 20, (here, off_pixels(-0.003), off_pixels(0.003))
 
 
-def _render_gif_sized(scene, t):
-    """Oracle frame of a resting camera at clock t, box-filtered from the grab size down to the GIFs' 800x429."""
-    scene.set_camera((0, 0, 0), t)
+def _render_gif_sized(scene, t, v=(0, 0, 0)):
+    """Oracle frame of a camera (at rest unless v is given) at clock t, box-filtered from the grab size down to the GIFs' 800x429."""
+    scene.set_camera(v, t)
     scene.update_objects()
     px, _, _ = oracle_ffi.render(scene, CLIENT_W, CLIENT_H, want_rgb=False)
     img = px["rgba"].reshape(CLIENT_H, CLIENT_W, 4)[::-1, :, :3]
@@ -199,6 +199,23 @@ def test_reference_gif_ladder_paradox_moving_objects():
         err = {dt: np.abs(_render_gif_sized(scene, t + dt)[crop] - ref).mean() for dt in (-0.2, 0.0, 0.2)}
         assert err[0.0] < 4.5, (f, err)
         assert err[-0.2] > 1.15 * err[0.0] and err[0.2] > 1.15 * err[0.0], (f, err)
+
+
+def test_reference_gif_ladder_paradox_from_the_moving_ladder():
+    """Screenshots/ladder_paradox_ladder_frame.gif: the same scene seen from a camera that moves with the ladder at 0.9c
+    (README.md:105-107), light propagation off: a MOVING CAMERA and MOVING OBJECTS together (the garage's ruler and walls pass
+    at 0.9c, the doors move diagonally and come out slanted: relativity of simultaneity).  At v = tanh(7361/5000) c three
+    frames 40 GIF frames apart fit clocks 1.575 s apart — 39.4 ms per GIF frame, the file's frame time — and each matches
+    better there than 0.1 s earlier or later, and by more than 12% than 0.4 s away."""
+    from conftest import LADDER_FRAME_CAMERA_V
+    scene = Scene.from_file("ladder_paradox")
+    crop = (slice(150, 270), slice(60, 760))         # the corridor: both rulers and the doors
+    for _, f, t in REFERENCE_GIF_FRAMES["ladderframe"]:
+        ref = _load(f"ref_ladderframe_gif_frame{f}.png")[crop]
+        err = {dt: np.abs(_render_gif_sized(scene, t + dt, LADDER_FRAME_CAMERA_V)[crop] - ref).mean() for dt in (-0.4, -0.1, 0.0, 0.1, 0.4)}
+        assert err[0.0] < 3.5, (f, err)
+        assert err[-0.1] > err[0.0] and err[0.1] > err[0.0], (f, err)
+        assert err[-0.4] > 1.12 * err[0.0] and err[0.4] > 1.12 * err[0.0], (f, err)
 
 
 # SURVEY.md §8(a) "Per-primary-ray work [probe, 1920x1080]" — measured from the reference itself
