@@ -57,6 +57,11 @@ REFERENCE_SHOTS = {
     # with exactly that, EVERY pixel of the grab is within 1 LSB.  Pins the textured-sphere (u,v) of
     # opencl_kernel.cl:356-357 (atan2 / asin) and the bilinear fetch on a sphere.
     "sphere_stationary": dict(text="TTextures/soccer.jpg\nOs\n p0,0,5,2,0,1,0,2,2,2\n t0\n v0,0,0\nR\n", v=(0.0, 0.0, 0.0), t=0.0, interval=-1),
+    # "Moving sphere" (README.md:126-127): the same turned ball at 0.99c (the shipped file says 0.9c; 0.99c, 2 rad and the
+    # ball's place along its path — 0.99 x 4.5555 units past the origin, written here as a start at the origin and a clock
+    # of 4.5555 s; the grab cannot tell the two apart — were found by fit_reference_camera.py::fit_moving_sphere): 336 of
+    # 3.5 M pixels beyond 1 LSB.  Pins the boost of a textured sphere, its retarded position and the Terrell-rotated pattern.
+    "sphere_moving": dict(text="TTextures/soccer.jpg\nOs\n p0,0,5,2,0,1,0,2,2,2\n t0\n v0.99,0,0\nR\n", v=(0.0, 0.0, 0.0), t=4.5555, interval=-1),
     "shadows1": dict(scene="shadows", v=(0.0, 0.0, 0.0), t=6.157, interval=-1),
     "shadows2": dict(scene="shadows", v=(0.0, 0.0, 0.0), t=9.212, interval=-1),
     "shadows4": dict(scene="shadows", v=(0.0, 0.0, 0.0), t=18.229, interval=-1),

@@ -29,8 +29,10 @@ Results (kept in tests/conftest.py::REFERENCE_SHOTS; tests/test_oracle.py checks
   sphere_stationary.png (Scenes/soccer.txt with the ball at rest): the ball of the grab is turned against the scene
              file's; a search over 13 axes x 126 angles at quarter resolution, then over the angle in steps of 0.004 rad
              at full size, ends at EXACTLY `p0,0,5,2,0,1,0,2,2,2` (2 rad about y): 0 of 3 525 120 pixels off by more than
-             1 LSB; 40 000 at 2 +- 0.004 rad.  sphere_moving.png is not reproduced by any (angle about y, clock) pair
-             with the scene file's v = 0.9c and stays unpinned.
+             1 LSB; 40 000 at 2 +- 0.004 rad.  
+  sphere_moving.png: the same turned ball in motion, NOT at the shipped file's 0.9c but at 0.99c (fit_moving_sphere):
+             `v0.99,0,0`, ball 0.99 x 4.5555 units along its path -> 336 of 3 525 120 pixels off by more than 1 LSB, the
+             ball's outline identical to the pixel (283 634); > 10 000 off at +-0.4 ms, +-0.0001c or +-0.001 rad.
 The residual pixels of the cube grabs are crate-texture texels (the reference decodes box.jpg with CImg/libjpeg,
 the harness with Pillow) and silhouette pixels, as for the static cube1.png.
 """
@@ -107,8 +109,43 @@ def fit_sphere_rotation():
         print("sphere_stationary angle", ang, int((np.abs(frame(ang, (0, 1, 0), W, H) - ref).max(axis=2) > 1).sum()))
 
 
+def fit_moving_sphere():
+    """sphere_moving.png: the turned ball of sphere_stationary.png in motion, light propagation on.  Unknowns: the speed
+    and the clock (or, the same thing, how far along its path the ball is).  For each speed the clock follows from the
+    ball's centroid in the grab; the pattern (Terrell rotation) then tells the speeds apart."""
+    ref = grab("sphere_moving")
+    small = np.asarray(Image.fromarray(ref.astype(np.uint8)).resize((640, 344), Image.BOX)).astype(np.int16)
+
+    def frame(v, t, w, h, angle=2.0):
+        s = Scene()
+        s.inputScene("TTextures/soccer.jpg\nOs\n p0,0,5,%.6f,0,1,0,2,2,2\n t0\n v%.6f,0,0\nR\n" % (angle, v))
+        s.set_camera((0, 0, 0), t)
+        s.update_objects()
+        px, _, _ = oracle_ffi.render(s, w, h, want_rgb=False)
+        return px["rgba"].reshape(h, w, 4)[::-1, :, :3].astype(np.int16)
+
+    def centroid_x(img):
+        return np.nonzero(np.abs(img - img[0, 0]).max(axis=2) > 8)[1].mean()
+    target = centroid_x(small)
+    for v in (0.5, 0.7, 0.8, 0.9, 0.95, 0.98, 0.985, 0.99, 0.992, 0.995, 0.999):
+        lo, hi = 0.0, 12.0
+        for _ in range(13):
+            mid = 0.5 * (lo + hi)
+            lo, hi = (lo, mid) if centroid_x(frame(v, mid, 640, 344)) > target else (mid, hi)
+        t = 0.5 * (lo + hi)
+        print("sphere_moving coarse: v", v, "t", round(t, 4), "mean abs error", float(np.abs(frame(v, t, 640, 344) - small).mean()))
+    # -> 0.9: 2.4 (only with the ball turned 1.75 rad instead of 2), 0.95: 1.6, 0.99: 0.45, 0.995: 1.4.  Full size at 0.99c:
+    for t in (4.5551, 4.5553, 4.5554, 4.5555, 4.5556, 4.5557, 4.5559):
+        print("sphere_moving t", t, int((np.abs(frame(0.99, t, W, H) - ref).max(axis=2) > 1).sum()))     # 12395 5233 1563 336 1425 4935 12499
+    for v in (0.9899, 0.9901):
+        print("sphere_moving v", v, min(int((np.abs(frame(v, 4.5555 * 0.99 / v + k * 1e-4, W, H) - ref).max(axis=2) > 1).sum()) for k in (-1, 0, 1)))   # > 10 000
+    for a in (1.999, 2.001):
+        print("sphere_moving angle", a, int((np.abs(frame(0.99, 4.5555, W, H, a) - ref).max(axis=2) > 1).sum()))                                     # 23 000
+
+
 if __name__ == "__main__":
     fit_sphere_rotation()
+    fit_moving_sphere()
     # windows around the optima; the coarse stages (bounding box of the crate vs. clock, 8x box-filtered SSD of the
     # arch vs. clock at v = 0.95, then the valley rapidity + clock = const) are how the windows were found
     search("cube", "cube2", 0, 0, range(73600, 73860, 10), [0], (826, 1377))

@@ -37,8 +37,12 @@ bar; the client area is 2560x1377.
 
   sphere_stationary.png  Scenes/soccer.txt "Stationary sphere" (README.md:124-125): a textured sphere at rest, turned by
                          2 rad about y when the grab was taken (recovered by fit_reference_camera.py): sphere (u,v) through
-                         atan2/asin and the bilinear fetch.  sphere_moving.png could not be reproduced from any
-                         (rotation about y, clock) pair and stays out.
+                         atan2/asin and the bilinear fetch.
+  sphere_moving.png      "Moving sphere" (README.md:126-127): the same turned ball passing the resting camera with light
+                         propagation on — at 0.99c, not the 0.9c of the shipped file (fit_reference_camera.py::
+                         fit_moving_sphere): the boost of a textured sphere, its retarded position and Terrell-rotated
+                         pattern.  With `v0.99,0,0` and the ball 0.99 x 4.5555 units along its path, 336 of the grab's
+                         3 525 120 pixels are more than 1 LSB off.
 
 Written per image: an exact stride-4 subsample of the client area (every 4th pixel of every 4th row, no
 filtering) and one full-resolution crop of the part with the most detail.
@@ -59,6 +63,7 @@ CROPS = {
     "cube3": (826, 1377, 1000, 1620),    # the crate as seen with light delay (Terrell rotation)
     "arch2": (900, 1300, 960, 1600),     # brick floor under the arch: the most position-sensitive texture
     "sphere_stationary": (380, 1020, 960, 1600),   # the whole ball
+    "sphere_moving": (380, 1020, 960, 1600),       # the whole ball, seen at 0.99c with light delay
     "shadows1": (540, 980, 1200, 1720),  # the pear (mesh path), dimly lit from the left
     "shadows2": (540, 980, 1200, 1720),
     "shadows4": (540, 980, 1200, 1720),  # the pear lit from the right, its shadow on the wall, the light sphere

@@ -386,7 +386,7 @@ def test_frames_in_flight_share_one_scene():
         slots[k].close()
 
 
-@pytest.mark.parametrize("shot", ["arch1", "arch2", "cube1", "cube2", "cube3", "sphere_stationary", "shadows1", "shadows2", "shadows4", "shadows5"])
+@pytest.mark.parametrize("shot", ["arch1", "arch2", "cube1", "cube2", "cube3", "sphere_stationary", "sphere_moving", "shadows1", "shadows2", "shadows4", "shadows5"])
 def test_hip_frame_against_the_reference_screenshots(renderer, shot):
     """The HIP path at the camera states of the reference's own screenshots (tests/conftest.py::REFERENCE_SHOTS),
     2560x1377: identical to the oracle on every pixel, and compared DIRECTLY with the reference's window grab
@@ -410,6 +410,9 @@ def test_hip_frame_against_the_reference_screenshots(renderer, shot):
     elif shot == "sphere_stationary":      # textured sphere: (u,v) by atan2/asin + bilinear fetch, every pixel within 1 LSB
         crop = np.asarray(Image.open(os.path.join(GOLDEN, "ref_sphere_stationary_crop_y380_x960.png")).convert("RGB")).astype(np.int16)
         assert d.max() <= 1 and np.abs(img[380:1020, 960:1600] - crop).max() <= 1
+    elif shot == "sphere_moving":          # the same ball at 0.99c with light delay: 336 of 3.5 M pixels beyond 1 LSB
+        crop = np.asarray(Image.open(os.path.join(GOLDEN, "ref_sphere_moving_crop_y380_x960.png")).convert("RGB")).astype(np.int16)
+        assert (d > 1).sum() <= 30 and (np.abs(img[380:1020, 960:1600] - crop).max(axis=2) > 1).sum() <= 400
     elif shot.startswith("shadows"):
         assert (d > 1).sum() <= 8 and (d > 0).mean() < 1e-3
         y0, y1, x0, x1 = SHADOWS_CROP

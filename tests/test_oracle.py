@@ -119,6 +119,35 @@ def test_reference_screenshot_sphere_stationary_textured_sphere():
     assert (np.abs(off - ref_crop).max(axis=2) > 1).sum() > 20000
 
 
+def test_reference_screenshot_sphere_moving_boosted_textured_sphere():
+    """Screenshots/sphere_moving.png (README.md:126-127, "Moving sphere"): the ball of sphere_stationary.png passing the
+    resting camera with light propagation on: object boost, retarded position and the Terrell-rotated pattern of a
+    TEXTURED sphere.  The grab was taken at 0.99c (not the 0.9c of the shipped Scenes/soccer.txt) with the ball
+    0.99 x 4.5555 units along its path (REFERENCE_SHOTS): there 336 of the grab's 3.5 M pixels are more than 1 LSB off;
+    0.4 ms, 0.0001c or 0.001 rad away it is more than ten thousand."""
+    img = _render_top_down("sphere_moving")
+    d = np.abs(img[::4, ::4] - _load("ref_sphere_moving_stride4.png")).max(axis=2)
+    assert (d > 1).sum() <= 30, (d > 1).sum()
+    ref_crop = _load("ref_sphere_moving_crop_y380_x960.png")
+    here = (np.abs(img[380:1020, 960:1600] - ref_crop).max(axis=2) > 1).sum()
+    assert here <= 400, here
+    assert (np.abs(img - img[0, 0]).max(axis=2) > 8).sum() == 283634          # the ball's outline: the grab's own pixel count
+
+    def off(text=None, dt=0.0):
+        s = None
+        if text:
+            s = Scene()
+            s.inputScene(text)
+            s.set_camera((0, 0, 0), REFERENCE_SHOTS["sphere_moving"]["t"])
+            s.update_objects()
+        o = _render_top_down("sphere_moving", rows=(380, 1020), scene=s, dt=dt)[:, 960:1600]
+        return (np.abs(o - ref_crop).max(axis=2) > 1).sum()
+    text = REFERENCE_SHOTS["sphere_moving"]["text"]
+    assert off(dt=0.0004) > 10000 and off(dt=-0.0004) > 10000
+    assert off(text.replace("v0.99,", "v0.9901,")) > 8000
+    assert off(text.replace("p0,0,5,2,", "p0,0,5,2.001,")) > 10000
+
+
 def shadows_pear_mask():
     """Client-area pixels (top-down) whose primary ray hits the pear: the mesh object alone, light propagation off."""
     s = load_reference_shot("shadows1")
