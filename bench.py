@@ -213,8 +213,9 @@ def main():
                     help="N>1: frames whose planes travel in ONE gather (a collective costs as much host and launch time as a frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="after timing, compare rank 0's framebuffer with the oracle on a few row bands")
-    ap.add_argument("--gather", default=os.environ.get("RPT_GATHER", "plane3"), choices=["plane3", "plane4"],
-                    help="what is gathered with N>1: the colour plane at 3 B/pixel (constant alpha byte dropped) or at 4 B/pixel as rendered")
+    ap.add_argument("--gather", default=os.environ.get("RPT_GATHER", "plane3"), choices=["plane3", "plane4", "full16"],
+                    help="what is gathered with N>1: the colour plane at 3 B/pixel (constant alpha byte dropped), at 4 B/pixel as rendered, "
+                         "or the naive exchange of whole 16-byte pixels (SURVEY.md 8e: kept to measure against)")
     ap.add_argument("--dry-run", action="store_true", help="launch plumbing only (gloo, no device work): see the module docstring")
     args = ap.parse_args()
 
@@ -289,7 +290,7 @@ def main():
         else:
             root_run = 0 if split == "solo" else int(split)
     frame = rdist.FrameSharder(renderers, W, H, rank, n, force_gather=force_dist, pipeline=pipeline,
-                               plane_bytes=3 if args.gather == "plane3" else 4, root_run=root_run,
+                               plane_bytes={"plane3": 3, "plane4": 4, "full16": 16}[args.gather], root_run=root_run,
                                frames_per_exchange=args.frames_per_exchange)   # allocates outputs; N == 1 renders straight into the framebuffers
 
     animate = os.environ.get("RPT_BENCH_ANIMATE") == "1"     # rehearsal only: every frame differs (camera clock runs)
@@ -377,7 +378,7 @@ def main():
         elif frame.weighted or frame.solo:
             alg = 16 * W * min(frame.local_rows, H) + 320 * n_objects      # rank 0 writes its rows as 16 B/px framebuffer pixels
         else:
-            alg = 4 * W * frame.local_rows + 320 * n_objects        # what the render kernel writes (the wire carries plane_bytes/4 of it)
+            alg = (16 if frame.full16 else 4) * W * frame.local_rows + 320 * n_objects   # what the render kernel writes (the wire carries plane_bytes/4 of it)
         # Launches of consecutive frames overlap on the device: `overlap` = sum of launch durations / wall time of
         # the region = average number of launches running at once.  A launch's share of the device is then
         # duration / overlap, and achieved = bytes per launch / that (= bytes of all launches / wall time).

@@ -267,7 +267,10 @@ class FrameSharder:
         """`device`: where the output tensors live; default the current GPU.  A CPU device (tests/test_dist_gloo.py:
         gloo, stand-in renderers) runs the same rotation and exchange without streams.
         `plane_bytes`: bytes per pixel on the wire — 3 (default: the alpha byte of a packed colour is the constant
-        1, so a small kernel drops it before the gather) or 4 (the rendered plane as it is).
+        1, so a small kernel drops it before the gather), 4 (the rendered plane as it is), or 16: the NAIVE exchange
+        SURVEY.md §8(e) asks to keep for comparison (`--gather=full16`) — every rank renders its tiles as whole 16-byte
+        pixels, copies them together, the gather carries 16 B/px (x and y of every pixel included, though they never
+        change), and the root copies each rank's tiles to their rows.  Equal split only.
         `root_run`: None = equal interleaved split (tile k -> rank k mod N, every plane gathered).  A power of two =
         the WEIGHTED split: per period of root_run + N - 1 tiles rank 0 renders root_run tiles straight into its
         framebuffer and rank j the single tile root_run + j - 1 into a 3 B/px plane — pixels rendered where they are
@@ -289,7 +292,8 @@ class FrameSharder:
         self.weighted = bool(self.root_run)
         if self.solo:
             self.exchange = False
-        assert plane_bytes in (3, 4) and not (self.weighted and plane_bytes != 3), "the weighted split exchanges 3-byte planes"
+        assert plane_bytes in (3, 4, 16) and not (self.weighted and plane_bytes != 3), "the weighted split exchanges 3-byte planes"
+        self.full16 = self.exchange and plane_bytes == 16
         self.plane_bytes, self.pipeline, self.depth = plane_bytes, pipeline, len(renderers)
         self.group = max(1, int(frames_per_exchange)) if self.exchange else 1
         self.frame, self.last, self.last_fb = 0, None, None
@@ -305,9 +309,11 @@ class FrameSharder:
             self.local_rows = local_tile_count(height, rank, world) * TILE_ROWS
         if self.solo:
             self.local_rows = tile_count(height) * TILE_ROWS if rank == 0 else 0
-        self.plane_unit = self.words * 3 if plane_bytes == 3 else self.words          # elements of one frame's plane on the wire
+        self.plane_unit = self.words * {3: 3, 4: 1, 16: 4}[plane_bytes]               # elements of one frame's plane on the wire
         wire_dtype = torch.uint8 if plane_bytes == 3 else torch.int32
-        renders_plane = self.exchange and not (self.weighted and rank == 0)            # the weighted root renders in place
+        renders_plane = self.exchange and not (self.weighted and rank == 0) and not self.full16   # the weighted root renders in place
+        self.tile_words = TILE_ROWS * width * 4                                        # int32 words of one tile of 16-byte pixels
+        padded_fb = tile_count(height) * self.tile_words                               # a framebuffer of whole tiles (full16 views it by tile)
 
         self.slots = []
         for r in renderers:
@@ -328,6 +334,10 @@ class FrameSharder:
                     r.set_tile_pattern(0, period, self.root_run, False)
                 else:
                     r.set_tile_pattern(self.root_run + rank - 1, period, 1, True)
+            elif self.full16:                     # its tiles as whole pixels, where they lie in a framebuffer of its own
+                r.set_rows(rank, world, False)
+                s.framebuffer = torch.zeros(padded_fb, dtype=torch.int32, device=dev)
+                r.set_output(s.framebuffer.data_ptr())
             else:
                 r.set_rows(rank, world, True)
             if renders_plane:
@@ -343,7 +353,8 @@ class FrameSharder:
                 b = _Batch()
                 b.send = torch.zeros(self.group * self.plane_unit, dtype=wire_dtype, device=dev)
                 b.recv = torch.zeros((world, self.group * self.plane_unit), dtype=wire_dtype, device=dev) if rank == 0 else None
-                b.fbs = [torch.zeros(width * height * 4, dtype=torch.int32, device=dev) for _ in range(self.group)] if rank == 0 else None
+                b.fbs = [torch.zeros(padded_fb if self.full16 else width * height * 4, dtype=torch.int32, device=dev)
+                         for _ in range(self.group)] if rank == 0 else None
                 b.ready = [torch.cuda.Event() for _ in range(self.group)] if self.on_gpu else None
                 b.done = torch.cuda.Event() if self.on_gpu else None
                 b.work, b.count = None, 0
@@ -358,7 +369,7 @@ class FrameSharder:
     def framebuffer(self):
         """Tensor holding the most recently submitted frame (16 B/pixel) on rank 0; complete after flush() + a device sync."""
         if self.exchange:
-            return self.last_fb
+            return self.last_fb[:self.W * self.H * 4] if (self.full16 and self.last_fb is not None) else self.last_fb
         return (self.last or self.slots[0]).framebuffer
 
     def render_and_gather(self, objects=None):
@@ -398,6 +409,16 @@ class FrameSharder:
                     unit.copy_(slot.plane, non_blocking=True)
             else:
                 unit.copy_(slot.plane)
+        if self.full16:                                     # this rank's tiles, 16 B/px, copied together
+            import torch
+            n_local = local_tile_count(self.H, self.rank, self.world)
+            unit = batch.send[k * self.plane_unit:(k + 1) * self.plane_unit].view(-1, self.tile_words)
+            mine = slot.framebuffer.view(-1, self.tile_words)[self.rank::self.world]
+            if self.on_gpu:
+                with torch.cuda.stream(slot.stream):
+                    unit[:n_local].copy_(mine, non_blocking=True)
+            else:
+                unit[:n_local].copy_(mine)
         if self.on_gpu:
             batch.ready[k].record(slot.stream)
         batch.count = k + 1
@@ -440,6 +461,11 @@ class FrameSharder:
                 src = batch.recv[:, k * self.plane_unit:(k + 1) * self.plane_unit]
                 # the k-th frame's planes lie (group * plane_unit) elements apart, one per rank
                 stride = batch.recv.shape[1] * batch.recv.element_size()
+                if self.full16:                # every rank's tiles back to their rows: N strided copies of whole pixels
+                    fb = batch.fbs[k].view(-1, self.tile_words)
+                    for j in range(self.world):
+                        fb[j::self.world].copy_(src[j].view(-1, self.tile_words)[:local_tile_count(self.H, j, self.world)], non_blocking=True)
+                    continue
                 if self.weighted:
                     self.r.scatter_helper_planes3(src.data_ptr(), batch.fbs[k].data_ptr(), self.W, self.H, self.world, self.root_run,
                                                   stride, stream=side)

@@ -196,7 +196,7 @@ def _sharder_worker(rank, world, port, W, H, frames, snap_path, out_path, plane_
                 return
             for f in range(first, first + count):
                 fb = sharder.slots[f % 3].framebuffer if sharder.solo else sharder.batches[(f // sharder.group) % 2].fbs[f % sharder.group]
-                seen[f] = fb.numpy().view(np.uint8).reshape(H * W, 16)[:, 8:12].copy().view(np.uint32)[:, 0]
+                seen[f] = fb.numpy()[:H * W * 4].view(np.uint8).reshape(H * W, 16)[:, 8:12].copy().view(np.uint32)[:, 0]   # (full16 pads to whole tiles)
 
         for f in range(frames):
             sharder.render_and_gather(snaps[f])
@@ -229,11 +229,11 @@ def test_three_byte_plane_round_trip():
 
 
 @pytest.mark.parametrize("world,plane_bytes,root_run,group", [(2, 3, None, 3), (3, 3, None, 1), (2, 4, None, 2), (2, 3, 4, 4), (3, 3, 2, 3),
-                                                              (3, 3, 1, 2), (2, 3, 0, 3), (2, 3, "auto", 3), (2, 3, 2, 4)])
+                                                              (3, 3, 1, 2), (2, 3, 0, 3), (2, 3, "auto", 3), (2, 3, 2, 4), (2, 16, None, 3), (3, 16, None, 2)])
 def test_frame_sharder_three_frames_in_flight(tmp_path, world, plane_bytes, root_run, group):
     """dist.FrameSharder itself, world 2 and 3 over gloo: three frame slots rotating over seven different frames
     (camera clock running), one gather per `group` frames (the last batch partial, sent by flush()) — of 3-byte
-    planes (the default) or of the 4-byte planes as rendered;
+    planes (the default), of the 4-byte planes as rendered, or of whole 16-byte pixels (the naive exchange, plane_bytes 16);
     with the equal split (root_run None), the weighted split (rank 0 renders root_run of every root_run + N - 1 tiles in
     place), rank 0 alone (0), and the split measured and agreed on by calibrate_split ("auto").  Rank 0's framebuffer
     after every frame must be that frame."""

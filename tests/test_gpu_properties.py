@@ -423,7 +423,7 @@ def test_hip_frame_against_the_reference_screenshots(renderer, shot):
         assert (d > 2).mean() < 5e-4
 
 
-@pytest.mark.parametrize("split", ["equal", "4", "auto"])
+@pytest.mark.parametrize("split", ["equal", "4", "auto", "full16"])
 def test_bench_exchange_path_over_rccl_with_one_rank(tmp_path, split):
     """bench.py's N > 1 frame path — colour planes, ONE RCCL gather per frame, root reassembly, three frames in
     flight — run as a real torch.distributed job of one rank (RPT_FORCE_DIST), camera clock running so that every
@@ -437,10 +437,12 @@ def test_bench_exchange_path_over_rccl_with_one_rank(tmp_path, split):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = {**os.environ, "RPT_FORCE_DIST": "1", "RPT_BENCH_ANIMATE": "1", "RPT_SPLIT": split}   # "4": the weighted split's root path
+    env = {**os.environ, "RPT_FORCE_DIST": "1", "RPT_BENCH_ANIMATE": "1", "RPT_SPLIT": "equal" if split == "full16" else split}   # "4": the weighted split's root path
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "14", "--warmup", "2",
            "--workload", "shadows", "--width", "1280", "--height", "720", "--no-cpu-baseline", "--check"]
+    if split == "full16":     # the naive exchange of whole 16-byte pixels, equal split
+        cmd += ["--gather", "full16"]
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
