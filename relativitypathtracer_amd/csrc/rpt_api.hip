@@ -283,7 +283,8 @@ void build_dobjs(const rpt_ctx *ctx, const rpt_object *objs, int count, rptd::DO
         }
         d.cbx = d.cby = d.cbz = 0.0f;
         float radius = -1.0f;
-        if (o.type == RPT_SPHERE) radius = 1.0f;
+        // (sphere: the float discriminant b^2 - c is off by up to ~1.5e-6 |oc|^2, see sphere_rect in rpt_screen_bounds.hpp)
+        if (o.type == RPT_SPHERE) radius = std::sqrt(1.0f + 1.5e-6f * (d.sphere_c + 1.0f));
         else if (o.type == RPT_CUBE) radius = 1.7320508f;
         else if (o.type == RPT_MESH && (size_t)o.meshIndex * 6 + 5 < ctx->geo->host_node_bounds.size()) {
             const float *nb = &ctx->geo->host_node_bounds[(size_t)o.meshIndex * 6];
@@ -291,6 +292,8 @@ void build_dobjs(const rpt_ctx *ctx, const rpt_object *objs, int count, rptd::DO
             const float ex = nb[3] - nb[0], ey = nb[4] - nb[1], ez = nb[5] - nb[2];
             radius = 0.5f * std::sqrt(ex * ex + ey * ey + ez * ez);
         }
+        // a relative gamma beyond 20: the float evaluation of the boosted direction is too noisy for this approximate test
+        finite = finite && std::isfinite(o.Lorentz[0].x) && std::fabs(o.Lorentz[0].x) <= 20.0f;
         d.rb = (finite && radius >= 0.0f && std::isfinite(radius)) ? radius * 1.02f + 1.0e-5f : -1.0f;
         out[i] = d;
     }

@@ -533,7 +533,9 @@ RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, H
     const f3 origin = transformPoint(obj.InvM, yzw(origin4));
     f3 dir = transformDirection(obj.InvM, yzw(dir4));
     if (V >= 20 && seg_max > 0.0f && obj.type != RPT_MESH) {
-        const float s = seg_max * 1.001f + 1.0e-4f, m = 1.002f;
+        // m: the intersectors' own float error grows with the origin's distance D (in object units) — the sphere's b^2 - c by up
+        // to ~1.5e-6 D^2 (so a "hit" can lie that much outside the unit sphere), the cube's slab products by ~4e-7 D
+        const float s = seg_max * 1.001f + 1.0e-4f, m = 1.002f + 0.75e-6f * dot(origin, origin);
         const f3 e = origin + dir * s;
         const bool apart = ((origin.x > m) & (e.x > m)) | ((origin.x < -m) & (e.x < -m)) |
                            ((origin.y > m) & (e.y > m)) | ((origin.y < -m) & (e.y < -m)) |

@@ -87,7 +87,7 @@ struct DirMap {
         if (interval == 0) {
             nd = {LsInv[0][0] * r[0] + LsInv[0][1] * r[1] + LsInv[0][2] * r[2], LsInv[1][0] * r[0] + LsInv[1][1] * r[1] + LsInv[1][2] * r[2],
                   LsInv[2][0] * r[0] + LsInv[2][1] * r[1] + LsInv[2][2] * r[2]};
-            return finite3(nd) && len(nd) > 0.0;
+            return finite3(nd) && dot(nd, nd) > 0.0;
         }
         // interval = -1: (interval, nd) is a past-directed null vector and stays one under Lorentz
         const double rl = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
@@ -95,19 +95,30 @@ struct DirMap {
         double c[4];
         for (int i = 0; i < 4; i++) c[i] = Linv[i][0] * k[0] + Linv[i][1] * k[1] + Linv[i][2] * k[2] + Linv[i][3] * k[3];
         nd = {c[1], c[2], c[3]};
-        return c[0] < 0.0 && finite3(nd) && len(nd) > 0.0;
+        return c[0] < 0.0 && finite3(nd) && dot(nd, nd) > 0.0;
     }
     D3 to_rest(D3 u) const {      // object-space direction -> direction in the object's rest frame
         return {M3[0][0] * u.x + M3[0][1] * u.y + M3[0][2] * u.z, M3[1][0] * u.x + M3[1][1] * u.y + M3[1][2] * u.z,
                 M3[2][0] * u.x + M3[2][1] * u.y + M3[2][2] * u.z};
     }
-    // G, verified through F: the angle between F(G(u)) and u must vanish
-    bool G_checked(D3 u, D3 &nd) const {
-        if (!G(u, nd)) return false;
+    // G, verified through F: the angle between F(G(u)) and u must vanish — against `tol`, the sine of an angle that is
+    // small next to the bounding shape's angular size as seen from the camera (an absolute tolerance says nothing when a
+    // strongly boosted object subtends 1e-3 rad in its own frame and half the screen in the camera's)
+    double tol = 1.0e-4;
+    bool verify(D3 u, D3 nd) const {
         const D3 back = F(nd);
         const double lb = len(back), lu = len(u);
         if (!(lb > 0.0) || !(lu > 0.0) || !std::isfinite(lb)) return false;
-        return dot(back, u) > 0.0 && len(cross(back, u)) <= 1.0e-4 * lb * lu;
+        return dot(back, u) > 0.0 && len(cross(back, u)) <= tol * lb * lu;
+    }
+    bool G_checked(D3 u, D3 &nd) const { return G(u, nd) && verify(u, nd); }
+    // The kernel evaluates F in float: the boosted null vector (-1, nd) has time and space parts of size gamma that cancel
+    // down to gamma (1 - beta cos) >= 1 / (2 gamma), so its direction carries a relative error of up to ~2 gamma^2 ulp.
+    // Is that small (half a percent) next to an angular size `ang` (radians, object space)?  If not, no statement is made.
+    bool float_noise_small_against(double ang) const {
+        if (interval == 0) return true;
+        const double g = L[0][0];
+        return std::isfinite(g) && 2.0e-7 * g * g <= 0.005 * ang;
     }
 };
 
@@ -158,7 +169,13 @@ struct Accum {
     void diag_point(double u, double v) {
         p_lo = std::min(p_lo, u + v); p_hi = std::max(p_hi, u + v); m_lo = std::min(m_lo, u - v); m_hi = std::max(m_hi, u - v);
     }
+    static bool in_window(double u, double v) { return u >= -DIAG_WINDOW_U && u <= DIAG_WINDOW_U && v >= -DIAG_WINDOW_V && v <= DIAG_WINDOW_V; }
     void diag_segment(double ua, double va, double ub, double vb) {      // Liang-Barsky clip to the window, then both end points
+        if (in_window(ua, va) && in_window(ub, vb)) {       // the usual case: nothing to clip (the window is convex)
+            diag_point(ua, va);
+            diag_point(ub, vb);
+            return;
+        }
         double t0 = 0.0, t1 = 1.0;
         const double du = ub - ua, dv = vb - va;
         const double pp[4] = {-du, du, -dv, dv}, qq[4] = {ua + DIAG_WINDOW_U, DIAG_WINDOW_U - ua, va + DIAG_WINDOW_V, DIAG_WINDOW_V - va};
@@ -175,7 +192,7 @@ struct Accum {
     void pen_up() { pen = false; }
     // the next point of the current polyline (a direction in front of the camera): box, and the segment from the last one
     void point(D3 nd) {
-        const double u = 0.5 * nd.x / nd.z, v = 0.5 * nd.y / nd.z;
+        const double iz = 0.5 / nd.z, u = nd.x * iz, v = nd.y * iz;
         u0 = std::min(u0, u); u1 = std::max(u1, u); v0 = std::min(v0, v); v1 = std::max(v1, v);
         if (pen) diag_segment(pen_u, pen_v, u, v);
         else diag_segment(u, v, u, v);
@@ -186,7 +203,8 @@ struct Accum {
     int n_crossings = 0;
     explicit Accum(const DirMap &map) : m(map) {}
 
-    static double frontness(D3 nd) { return nd.z - EPS_FRONT * len(nd); }
+    // in front of the clip cone: nd.z > EPS |nd|, without the square root
+    static bool is_front(D3 nd) { return nd.z > 0.0 && nd.z * nd.z > EPS_FRONT * EPS_FRONT * dot(nd, nd); }
     void take(D3 nd) {      // a lone direction in front of the camera (horizon samples: far outside the diagonal window)
         const double u = 0.5 * nd.x / nd.z, v = 0.5 * nd.y / nd.z;
         u0 = std::min(u0, u); u1 = std::max(u1, u); v0 = std::min(v0, v); v1 = std::max(v1, v);
@@ -200,8 +218,8 @@ struct Accum {
         return true;
     }
     void classify(D3 nd, bool &front) {
-        front = frontness(nd) > 0.0;
-        if (!front && nd.z > -0.2 * len(nd)) any_near_behind = true;
+        front = is_front(nd);
+        if (!front && (nd.z >= 0.0 || nd.z * nd.z < 0.04 * dot(nd, nd))) any_near_behind = true;      // nd.z > -0.2 |nd|
     }
     // one more sample of the polyline being drawn, after map_sample/classify (and crossing(), if the side changed)
     void feed(D3 nd, bool front) {
@@ -212,11 +230,11 @@ struct Accum {
     // object-space segment between them (exact for straight edges, close enough for arcs: the margin covers it)
     void crossing(D3 ua, D3 ub, bool front_a) {
         D3 lo = ua, hi = ub;      // lo keeps ua's side, hi ub's
-        for (int it = 0; it < 18; it++) {
+        for (int it = 0; it < 12; it++) {
             const D3 mid = mul(add(lo, hi), 0.5);
             D3 nd;
             if (!m.G(mid, nd)) { failed = true; return; }
-            const bool f = frontness(nd) > 0.0;
+            const bool f = is_front(nd);
             if (f == front_a) lo = mid; else hi = mid;
         }
         const D3 cross_u = front_a ? lo : hi, from_u = front_a ? ua : ub;      // the front side of the crossing; the front sample
@@ -233,7 +251,7 @@ struct Accum {
                 const D3 u = add(mul(cross_u, 1.0 - w), mul(from_u, w));
                 D3 n2;
                 if (!m.G(u, n2)) { failed = true; return; }
-                if (frontness(n2) > 0.0) way[n_way++] = n2;
+                if (is_front(n2)) way[n_way++] = n2;
             }
         }
         if (front_a) {              // the pen stands on the front sample: ... -> way[0] -> ... -> crossing, and up
@@ -268,6 +286,11 @@ struct Accum {
         }
         return count;
     }
+    // An outline that lies wholly in front of the clip cone is a closed curve inside the front cap; the kept region is one of
+    // the two parts it cuts the direction sphere into — the one inside the cap, or (under strong aberration) the one that
+    // holds everything else, the horizon and the whole back cap included.  ONE direction of the back cap tells which.
+    template <class Inside>
+    bool wraps_behind(Inside inside) const { return inside(m.F(D3{0.0, 0.0, -1.0})); }
     // The diagonal extents are those of (region ∩ window): besides the outline clipped to the window, that set's boundary
     // can run along the window's own edges, where u + v and u - v are monotone — so it ends in a window corner (asked here)
     // or where the outline crosses the edge (already taken with the clipped outline).
@@ -336,7 +359,7 @@ inline bool ray_meets_box(const double oc[3], D3 d, const double lo[3], const do
 // Box [bmin, bmax] in object space (cube: +-1; mesh: the root node's bounds).
 inline Rect box_rect(const rpt_object &o, int interval, const double bmin[3], const double bmax[3]) {
     using namespace detail;
-    const DirMap m = make_map(o, interval);
+    DirMap m = make_map(o, interval);
     if (!m.ok) return full_rect();
     const D3 cam{o.stationaryCam.y, o.stationaryCam.z, o.stationaryCam.w};
     const D3 oc{o.InvM[0].x * cam.x + o.InvM[0].y * cam.y + o.InvM[0].z * cam.z + o.InvM[0].w,
@@ -353,7 +376,8 @@ inline Rect box_rect(const rpt_object &o, int interval, const double bmin[3], co
         diag2 += (hi[a] - lo[a]) * (hi[a] - lo[a]);
     }
     if (inside) return full_rect();
-    (void)diag2;
+    // the slab test's float error grows with the distance in box units: 4e-7 |oc| against the 5 % the box is inflated by
+    if (dot(oc, oc) > 1.0e8 * std::max(1.0e-300, diag2)) return full_rect();
     // Which faces does oc see?  +1 seen, -1 hidden, 0 too close to the face's plane to say.  The outline of a convex box is
     // made of the edges between a seen and a hidden face; only those are sampled (edges between two seen or two hidden
     // faces lie inside the outline: taking or leaving them changes nothing).
@@ -370,7 +394,20 @@ inline Rect box_rect(const rpt_object &o, int interval, const double bmin[3], co
     D3 cu[8], cnd[8];
     for (int k = 0; k < 8; k++) {
         cu[k] = sub(D3{(k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2]}, oc);
-        if (!((k == 0 || k == 7) ? m.G_checked(cu[k], cnd[k]) : m.G(cu[k], cnd[k]))) return full_rect();
+        if (!m.G(cu[k], cnd[k])) return full_rect();
+    }
+    {   // the box's angular radius as seen from oc sets the tolerance of that check (and of every later one)
+        double cmin = 1.0;
+        const D3 centre = sub(D3{0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])}, oc);
+        const double lc = len(centre);
+        for (int k = 0; k < 8 && lc > 0.0; k++) {
+            const double lk = len(cu[k]);
+            if (lk > 0.0) cmin = std::min(cmin, dot(cu[k], centre) / (lk * lc));
+        }
+        const double ang = std::acos(std::max(-1.0, std::min(1.0, cmin)));
+        if (!m.float_noise_small_against(ang)) return full_rect();
+        m.tol = std::min(1.0e-4, 5.0e-3 * ang);
+        if (!m.verify(cu[0], cnd[0]) || !m.verify(cu[7], cnd[7])) return full_rect();
     }
     if (!m.linear) {
         // How far an aberrated edge bends away from its chord: an edge that spans the angle theta (seen from the camera, in the
@@ -389,6 +426,8 @@ inline Rect box_rect(const rpt_object &o, int interval, const double bmin[3], co
         const double g = m.L[0][0], gb = g > 1.0 ? std::sqrt(g * g - 1.0) : 0.0;
         const double want = std::sqrt(std::max(0.0, theta * gb / 8.0 / 0.005));
         S = want <= 2.0 ? 2 : (want <= 4.0 ? 4 : 8);
+        for (int k = 0; k < 8; k++)
+            if (!Accum::is_front(cnd[k])) S = 16;      // a corner behind the clip cone: the outline is clipped, sample finely at once
     }
     Accum acc(m);
     bool clipped = false;
@@ -426,15 +465,15 @@ resample:
         acc = Accum(m);
         goto resample;
     }
-    // the horizon: coarse when the whole outline is in front of the camera (it then only guards against a region that
-    // wraps around behind the camera, which strong aberration can produce), fine when the outline is clipped
+    // the horizon: when the whole outline is in front of the camera only a region that wraps around behind the camera can
+    // reach it (strong aberration can produce one; wraps_behind asks); always when the outline is clipped
     double blo[3], bhi[3];
     for (int a = 0; a < 3; a++) { const double g = 0.05 * (hi[a] - lo[a]) + 1.0e-4; blo[a] = lo[a] - g; bhi[a] = hi[a] + g; }
     auto inside_box = [&](D3 d) { return !finite3(d) || ray_meets_box(p, d, blo, bhi); };
     if (!clipped) {
         // (a linear map keeps the cone of kept directions convex: with its whole outline in front of the camera it cannot
         // reach the horizon, so only aberrated outlines are asked)
-        if (!m.linear && acc.horizon(8, inside_box) > 0) acc.horizon(32, inside_box);
+        if (!m.linear && acc.wraps_behind(inside_box)) acc.horizon(32, inside_box);
     } else {
         acc.horizon(32, inside_box);
     }
@@ -445,17 +484,24 @@ resample:
 // Unit sphere at the object-space origin.
 inline Rect sphere_rect(const rpt_object &o, int interval) {
     using namespace detail;
-    const DirMap m = make_map(o, interval);
+    DirMap m = make_map(o, interval);
     if (!m.ok) return full_rect();
     const D3 cam{o.stationaryCam.y, o.stationaryCam.z, o.stationaryCam.w};
     const D3 oc{o.InvM[0].x * cam.x + o.InvM[0].y * cam.y + o.InvM[0].z * cam.z + o.InvM[0].w,
                 o.InvM[1].x * cam.x + o.InvM[1].y * cam.y + o.InvM[1].z * cam.z + o.InvM[1].w,
                 o.InvM[2].x * cam.x + o.InvM[2].y * cam.y + o.InvM[2].z * cam.z + o.InvM[2].w};
     const double dist = len(oc);
-    const double rb = 1.02;                                    // inflated radius
-    if (!finite3(oc) || !(dist > 1.1 * rb)) return full_rect();
+    // inflated radius.  The kernel decides a hit by the sign of b^2 - c in float with c = |oc|^2 - 1 (opencl_kernel.cl:341-345):
+    // both terms are of size |oc|^2 and each carries a few ulp, so the discriminant is off by up to ~1.5e-6 |oc|^2 — for a
+    // camera that is hundreds of radii away in the object's frame (a strongly boosted sphere) the float sphere is visibly
+    // larger or smaller than the exact one.  The rim is taken from a sphere that is larger by that bound.
+    if (!finite3(oc) || !std::isfinite(dist)) return full_rect();
+    const double rb = 1.02 * std::sqrt(1.0 + 1.5e-6 * dist * dist);
+    if (!(dist > 1.1 * rb) || dist > 5.0e4) return full_rect();      // (beyond 5e4 radii the float direction itself is too coarse)
     const D3 axis = mul(oc, -1.0 / dist);
     const double sa = rb / dist, ca = std::sqrt(1.0 - sa * sa);
+    if (!m.float_noise_small_against(sa)) return full_rect();
+    m.tol = std::min(1.0e-4, 5.0e-3 * sa);
     const D3 helper = std::fabs(axis.x) < 0.6 ? D3{1, 0, 0} : D3{0, 1, 0};
     D3 e1 = cross(axis, helper);
     e1 = mul(e1, 1.0 / len(e1));
@@ -489,7 +535,7 @@ inline Rect sphere_rect(const rpt_object &o, int interval) {
         return !finite3(d) || !(l > 0.0) || dot(d, axis) >= cos_in * l;
     };
     if (!clipped) {
-        if (!m.linear && acc.horizon(8, inside_cone) > 0) acc.horizon(32, inside_cone);
+        if (!m.linear && acc.wraps_behind(inside_cone)) acc.horizon(32, inside_cone);
     } else {
         acc.horizon(32, inside_cone);
     }

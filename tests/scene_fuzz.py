@@ -53,3 +53,32 @@ def random_scene_text(rng):
         lines.append("I")
     lines.append("R")
     return "\n".join(lines) + "\n", has_textured_sphere
+
+
+def extreme_scene_text(rng):
+    """Objects at 0.5c .. 0.9999c in random directions, some of them far away or tiny (the camera then stands hundreds or
+    thousands of radii away in the object's own frame), lights among them, light propagation on or off: the regime where the
+    kernel's float arithmetic itself gets coarse (the sphere's discriminant, the boosted null direction) and every
+    conservative cull has to allow for that."""
+    lines = ["MModels/cube.obj"]
+    for k in range(int(rng.integers(1, 4))):
+        kind = rng.choice(["s", "c", "m0"])
+        lines.append("O" + kind)
+        far = rng.choice([1.0, 1.0, 10.0, 60.0])
+        pos = rng.uniform([-8, -5, -6], [8, 5, 20]) * far
+        sc = rng.uniform(0.3, 3.0, size=3) * rng.choice([0.02, 0.3, 1.0, 1.0, 5.0])
+        ang = float(rng.uniform(-3, 3))
+        axis = rng.normal(size=3)
+        lines.append(" p" + ",".join(f"{v:.4f}" for v in [*pos, ang, *axis, *sc]))
+        lines.append(" c1,1,1")
+        if rng.random() < 0.3:
+            lines.append(" l1")
+        if rng.random() < 0.85:
+            v = rng.normal(size=3)
+            v = v / np.linalg.norm(v) * rng.choice([0.5, 0.9, 0.99, 0.999, 0.9999])
+            lines.append(" v" + ",".join(f"{c:.6f}" for c in v))
+    lines.append("A0.5")
+    if rng.random() < 0.4:
+        lines.append("I")
+    lines.append("R")
+    return "\n".join(lines) + "\n"

@@ -57,6 +57,38 @@ def test_random_scene(renderer, seed):
         assert np.array_equal(px["rgba"], opx["rgba"]), f"seed {seed} variant {variant}: packed bytes differ\n{text}"
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RPT_EXTREME_FIRST", "0")), int(os.environ.get("RPT_EXTREME_LAST", "32"))))
+def test_extreme_scene(renderer, seed):
+    """scene_fuzz.extreme_scene_text: relative gammas of several hundred, cameras thousands of radii away in an object's own
+    frame, lights among the objects.  Bit-identical to the oracle through the culled default, the reference-layout kernel, the
+    un-culled kernel and round 1's prepass kernel — i.e. neither the screen bounds nor the shadow-segment cull may assume
+    more precision than the intersectors' float arithmetic has there."""
+    from scene_fuzz import extreme_scene_text
+    rng = np.random.default_rng(550000 + seed)
+    text = extreme_scene_text(rng)
+    scene = Scene()
+    scene.inputScene(text)
+    v = rng.normal(size=3)
+    v = v / np.linalg.norm(v) * rng.choice([0.0, 0.5, 0.9, 0.99, 0.999])
+    scene.set_camera(tuple(float(c) for c in v), float(rng.uniform(-5, 40)))
+    scene.update_objects()
+    W, H = [(320, 184), (256, 144), (200, 150)][seed % 3]
+    opx, orgb, _ = oracle_ffi.render(scene, W, H)
+    for variant in (0, 1, 3, 26):
+        renderer.set_variant(variant)
+        renderer.upload_scene(scene)
+        renderer.set_scene_params(scene, W, H)
+        renderer.set_rows(0, 1, False)
+        renderer.set_output(None)
+        renderer.set_debug_rgb(True)
+        renderer.render()
+        px, rgb = renderer.read_framebuffer(), renderer.read_debug_rgb()
+        assert np.array_equal(np.isfinite(rgb), np.isfinite(orgb)), f"extreme seed {seed} variant {variant}\n{text}"
+        same = (rgb.view(np.uint32) == orgb.view(np.uint32)) | (np.isnan(rgb) & np.isnan(orgb))
+        assert same.all(), f"extreme seed {seed} variant {variant}: {int((~same).sum())} float RGB values not bit-identical\n{text}"
+        assert np.array_equal(px["rgba"], opx["rgba"]), f"extreme seed {seed} variant {variant}: packed bytes differ\n{text}"
+
+
 @pytest.mark.parametrize("round_", range(int(os.environ.get("RPT_FUZZ_ROUNDS", "8"))))
 def test_random_scenes_three_in_flight(round_):
     """Three contexts render three DIFFERENT random scenes at once (submitted back to back, nothing waited for in

@@ -132,6 +132,24 @@ def test_rectangles_contain_every_hit_shipped_scenes_random_cameras():
         check_scene(s, W, H, f"trial {trial} {name} {W}x{H} v={v} t={t}")
 
 
+@pytest.mark.parametrize("seed", range(32))
+def test_rectangles_contain_every_hit_extreme_boosts(seed):
+    """Objects at up to 0.9999c seen from cameras at up to 0.999c, far away or tiny: relative gammas of several hundred, the
+    camera thousands of radii away in the object's own frame.  There the kernel's FLOAT arithmetic decides where an object
+    appears (a sphere's discriminant b^2 - c loses all its digits; the boosted null direction cancels), and the bounds must
+    contain what the float kernel hits, not the exact outline (the oracle computes in the same floats).  9 000 more such scenes
+    in a soak run; the 14 failures that run found in the first version of the bounds were all spheres far from the camera."""
+    from scene_fuzz import extreme_scene_text
+    rng = np.random.default_rng(550000 + seed)
+    scene = Scene()
+    scene.inputScene(extreme_scene_text(rng))
+    v = rng.normal(size=3)
+    v = v / np.linalg.norm(v) * rng.choice([0.0, 0.5, 0.9, 0.99, 0.999])
+    scene.set_camera(tuple(float(c) for c in v), float(rng.uniform(-5, 40)))
+    scene.update_objects()
+    check_scene(scene, 160, 90, f"extreme {seed}")
+
+
 ADVERSARIAL = [
     # huge and tiny scales, a slab seen edge-on, a box the camera stands on, one it is inside of, a sphere it touches
     "Oc\n p0,0,8,0,0,1,0,1000,1000,0.001\n c1,1,1\nOs\n p0.5,0.2,3,0,0,1,0,0.0001,0.0001,0.0001\n c1,1,1\nA0.5\nR\n",
