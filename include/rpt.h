@@ -196,8 +196,10 @@ int rpt_read_wave_times(rpt_ctx *ctx, unsigned long long *out, size_t max_words,
 
 /* GPU octree build (replaces Mesh::GenerateOctree, Mesh.cpp:5-28, and Subdivide, Octree.cpp:171-248): builds the
  * octree of the mesh whose triangles start at word `first_triangle_word` of `triangles` (the root lists every
- * triangle imported so far, as the reference's does).  The triangle/box classification runs on the device;
- * the result — node order, lists, neighbour links — is byte-identical to the host builder's.  Node and list
+ * triangle imported so far, as the reference's does).  All levels run on the device in one submission on the context's
+ * stream (stop rule, split decisions, triangle/box classification, ordered lists); the call waits once, reads the levels
+ * back and numbers them as the reference does: node order, lists, neighbour links are byte-identical to the host builder's.
+ * (RPT_OCTREE_TIMING=1 in the environment prints the call's phases to stderr.)  Node and list
  * indices in the output are absolute, based at node_index_base / tri_index_base (the current lengths of the
  * host's octree and octreeTris arrays).  The two arrays are malloc()ed; release them with rpt_free_host. */
 int rpt_build_octree(rpt_ctx *ctx, const rpt_float3 *vertices, size_t vertex_count, const uint32_t *triangles,

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -1034,10 +1035,9 @@ extern "C" int rpt_build_octree(rpt_ctx *ctx, const rpt_float3 *vertices, size_t
     RPT_HIP(ctx, hipSetDevice(ctx->device));
 
     // root (Mesh.cpp:6-21): bounds over this mesh's face-corner vertices, list = every triangle imported so far
-    std::vector<std::vector<BuildNode>> levels(1);
-    std::vector<std::vector<int32_t>> lists(1);       // host copies of every level's concatenated lists
+    rptb::BNode root;
+    std::memset(&root, 0, sizeof root);
     {
-        BuildNode root;
         const rpt_float3 v0 = vertices[triangles[first_triangle_word]];
         root.mn[0] = root.mx[0] = v0.x; root.mn[1] = root.mx[1] = v0.y; root.mn[2] = root.mx[2] = v0.z;
         for (size_t i = first_triangle_word / 3; i < triangle_words / 3; i++) {
@@ -1052,9 +1052,15 @@ extern "C" int rpt_build_octree(rpt_ctx *ctx, const rpt_float3 *vertices, size_t
         root.list_count = (unsigned int)n_tris_total;
         root.min_tris = 0;
         root.depth = 6;
-        levels[0].push_back(root);
-        lists[0].resize(n_tris_total);
-        for (size_t t = 0; t < n_tris_total; t++) lists[0][t] = (int32_t)t;
+        root.first_child = -1;
+        root.valence = 0;
+    }
+    const int max_depth = root.depth;                                  // levels 0 .. max_depth
+    size_t level_nodes[8], node_offset[8], nodes_total = 0;           // at most 8^level nodes on a level
+    for (int l = 0; l <= max_depth; l++) {
+        level_nodes[l] = (size_t)1 << (3 * l);
+        node_offset[l] = nodes_total;
+        nodes_total += level_nodes[l];
     }
 
     DevTemp d_vertices, d_triangles;
@@ -1063,111 +1069,118 @@ extern "C" int rpt_build_octree(rpt_ctx *ctx, const rpt_float3 *vertices, size_t
     RPT_HIP(ctx, hipMemcpy(d_vertices.p, vertices, vertex_count * sizeof(rpt_float3), hipMemcpyHostToDevice));
     RPT_HIP(ctx, hipMemcpy(d_triangles.p, triangles, triangle_words * sizeof(uint32_t), hipMemcpyHostToDevice));
 
-    std::vector<int> vertex_hits(vertex_count, 0);
-    for (size_t l = 0; l < levels.size(); l++) {
-        std::vector<BuildNode> &nodes = levels[l];
-        const std::vector<int32_t> &list = lists[l];
-        std::vector<rptb::ChildDesc> children;
-        std::vector<unsigned int> chunk_child;
-        unsigned int flag_total = 0;
-        for (BuildNode &n : nodes) {
-            if (n.depth <= 0 || (int)n.list_count <= n.min_tris) continue;      // Octree.cpp:172
-            // stop rule for the children: most triangles of this node around one vertex (Octree.cpp:180-190)
-            int valence = 0;
-            for (unsigned int i = 0; i < n.list_count; i++)
-                for (int k = 0; k < 3; k++) {
-                    const int c = ++vertex_hits[triangles[9 * list[n.list_begin + i] + 3 * k]];
-                    valence = c > valence ? c : valence;
-                }
-            for (unsigned int i = 0; i < n.list_count; i++)
-                for (int k = 0; k < 3; k++) vertex_hits[triangles[9 * list[n.list_begin + i] + 3 * k]] = 0;
-            n.valence = valence;
-            n.first_child = (int)children.size();
-            const float hx = (n.mx[0] - n.mn[0]) / 2, hy = (n.mx[1] - n.mn[1]) / 2, hz = (n.mx[2] - n.mn[2]) / 2;
-            for (int x = 0; x < 2; x++)
-                for (int y = 0; y < 2; y++)
-                    for (int z = 0; z < 2; z++) {       // creation order == child index z + 2y + 4x (Octree.cpp:191-201)
-                        rptb::ChildDesc c;
-                        // child.min = min + ex*x + ey*y + ez*z, component by component, zeros included
-                        c.minx = n.mn[0] + hx * (float)x + 0.0f * (float)y + 0.0f * (float)z;
-                        c.miny = n.mn[1] + 0.0f * (float)x + hy * (float)y + 0.0f * (float)z;
-                        c.minz = n.mn[2] + 0.0f * (float)x + 0.0f * (float)y + hz * (float)z;
-                        c.maxx = c.minx + hx; c.maxy = c.miny + hy; c.maxz = c.minz + hz;
-                        c.list_begin = n.list_begin;
-                        c.list_count = n.list_count;
-                        c.flag_base = flag_total;
-                        c.chunk_base = (unsigned int)chunk_child.size();
-                        flag_total += n.list_count;
-                        for (unsigned int k = 0; k < (n.list_count + 255) / 256; k++) chunk_child.push_back((unsigned int)children.size());
-                        children.push_back(c);
-                    }
-        }
-        if (children.empty()) break;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (std::getenv("RPT_OCTREE_TIMING")) { auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "  octree %-10s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; } };
+    std::vector<std::vector<BuildNode>> levels;
+    std::vector<std::vector<int32_t>> lists;          // host copies of every level's concatenated lists
+    // One submission per attempt; an attempt whose lists outgrow `cap` entries per level says so in the header and is repeated.
+    size_t cap = std::max<size_t>(16 * n_tris_total, 4096);
+    if (const char *e = std::getenv("RPT_OCTREE_LIST_CAP"))            // test hook: start small, so that the repeat path runs
+        cap = std::max<size_t>(n_tris_total, (size_t)std::strtoull(e, nullptr, 10));
+    for (int attempt = 0;; attempt++) {
+        if (8 * cap > 0xffffffffull) return fail(ctx, RPT_ERR_NOMEM, "rpt_build_octree: triangle lists exceed what the builder indexes with 32 bits");
+        size_t hash_slots = 1;
+        while (hash_slots < 6 * cap) hash_slots <<= 1;                 // three vertex occurrences per entry, at most half full
+        const size_t chunk_cap = cap / 32 + level_nodes[max_depth] + 8; // 8 * (entries / 256 + splitting nodes), rounded up
+        // one arena for everything the levels need
+        size_t arena_bytes = 0;
+        auto carve = [&](size_t bytes) { const size_t at = arena_bytes; arena_bytes += (bytes + 255) & ~(size_t)255; return at; };
+        const size_t o_hdr = carve(sizeof(rptb::BuildHeader)), o_nodes = carve(nodes_total * sizeof(rptb::BNode)),
+                     o_lists = carve((size_t)(max_depth + 1) * cap * sizeof(int32_t)), o_children = carve(level_nodes[max_depth] * sizeof(rptb::ChildDesc)),
+                     o_split = carve(level_nodes[max_depth] / 8 * sizeof(unsigned int) + 16), o_flags = carve(8 * cap + 16),
+                     o_counts = carve(chunk_cap * sizeof(unsigned int)), o_chunk_out = carve(chunk_cap * sizeof(unsigned int)),
+                     o_keys = carve(hash_slots * sizeof(unsigned long long)), o_hits = carve(hash_slots * sizeof(unsigned int));
+        DevTemp arena;
+        RPT_HIP(ctx, hipMalloc(&arena.p, arena_bytes));
+        struct Part { void *p; } d_hdr{(char *)arena.p + o_hdr}, d_nodes{(char *)arena.p + o_nodes}, d_lists{(char *)arena.p + o_lists},
+            d_children{(char *)arena.p + o_children}, d_split{(char *)arena.p + o_split}, d_flags{(char *)arena.p + o_flags},
+            d_counts{(char *)arena.p + o_counts}, d_chunk_out{(char *)arena.p + o_chunk_out}, d_keys{(char *)arena.p + o_keys},
+            d_hits{(char *)arena.p + o_hits};
+        lap("alloc");
+        rptb::BNode *nodes_dev = (rptb::BNode *)d_nodes.p;
+        int32_t *lists_dev = (int32_t *)d_lists.p;
+        rptb::BuildHeader *hdr_dev = (rptb::BuildHeader *)d_hdr.p;
 
-        // device: classify (child, parent entry), count per chunk, compact in order
-        const unsigned int n_chunks = (unsigned int)chunk_child.size();
-        DevTemp d_list, d_children, d_chunk_child, d_flags, d_counts, d_chunk_out, d_next;
-        RPT_HIP(ctx, hipMalloc(&d_list.p, list.size() * sizeof(int32_t)));
-        RPT_HIP(ctx, hipMalloc(&d_children.p, children.size() * sizeof(rptb::ChildDesc)));
-        RPT_HIP(ctx, hipMalloc(&d_chunk_child.p, n_chunks * sizeof(unsigned int)));
-        RPT_HIP(ctx, hipMalloc(&d_flags.p, (size_t)flag_total + 16));
-        RPT_HIP(ctx, hipMalloc(&d_counts.p, n_chunks * sizeof(unsigned int)));
-        RPT_HIP(ctx, hipMalloc(&d_chunk_out.p, n_chunks * sizeof(unsigned int)));
-        RPT_HIP(ctx, hipMemcpy(d_list.p, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        RPT_HIP(ctx, hipMemcpy(d_children.p, children.data(), children.size() * sizeof(rptb::ChildDesc), hipMemcpyHostToDevice));
-        RPT_HIP(ctx, hipMemcpy(d_chunk_child.p, chunk_child.data(), n_chunks * sizeof(unsigned int), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(rptb::sat_flag_kernel, dim3(n_chunks), dim3(256), 0, ctx->stream, (const rpt_float3 *)d_vertices.p,
-                           (const uint32_t *)d_triangles.p, (const int32_t *)d_list.p, (const rptb::ChildDesc *)d_children.p,
-                           (const unsigned int *)d_chunk_child.p, (unsigned char *)d_flags.p, (unsigned int *)d_counts.p, n_chunks);
+        rptb::BuildHeader hdr;
+        std::memset(&hdr, 0, sizeof hdr);
+        hdr.n_nodes[0] = 1;
+        hdr.list_len[0] = (unsigned int)n_tris_total;
+        RPT_HIP(ctx, hipMemcpyAsync(hdr_dev, &hdr, sizeof hdr, hipMemcpyHostToDevice, ctx->stream));
+        RPT_HIP(ctx, hipMemcpyAsync(nodes_dev, &root, sizeof root, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(rptb::iota_kernel, dim3((unsigned int)((n_tris_total + 255) / 256)), dim3(256), 0, ctx->stream, lists_dev,
+                           (unsigned int)n_tris_total);
+        const unsigned int entry_blocks = (unsigned int)((cap + 255) / 256);
+        for (int l = 0; l < max_depth; l++) {
+            rptb::BNode *nodes_l = nodes_dev + node_offset[l], *nodes_next = nodes_dev + node_offset[l + 1];
+            int32_t *list_l = lists_dev + (size_t)l * cap, *list_next = lists_dev + (size_t)(l + 1) * cap;
+            const size_t chunks_l = std::min(chunk_cap, cap / 32 + level_nodes[l + 1] + 8);
+            RPT_HIP(ctx, hipMemsetAsync(d_keys.p, 0xff, hash_slots * sizeof(unsigned long long), ctx->stream));
+            RPT_HIP(ctx, hipMemsetAsync(d_hits.p, 0, hash_slots * sizeof(unsigned int), ctx->stream));
+            hipLaunchKernelGGL(rptb::valence_kernel, dim3(entry_blocks), dim3(256), 0, ctx->stream, (const uint32_t *)d_triangles.p,
+                               (const int32_t *)list_l, nodes_l, (const rptb::BuildHeader *)hdr_dev, l, (unsigned long long *)d_keys.p,
+                               (unsigned int *)d_hits.p, (unsigned int)(hash_slots - 1));
+            hipLaunchKernelGGL(rptb::split_kernel, dim3(1), dim3(1024), 0, ctx->stream, nodes_l, hdr_dev, l, (rptb::ChildDesc *)d_children.p,
+                               (unsigned int *)d_split.p, (unsigned int)level_nodes[l + 1]);
+            hipLaunchKernelGGL(rptb::sat_flag_kernel, dim3((unsigned int)chunks_l), dim3(256), 0, ctx->stream, (const rpt_float3 *)d_vertices.p,
+                               (const uint32_t *)d_triangles.p, (const int32_t *)list_l, (const rptb::ChildDesc *)d_children.p,
+                               (const rptb::BuildHeader *)hdr_dev, (unsigned char *)d_flags.p, (unsigned int *)d_counts.p);
+            hipLaunchKernelGGL(rptb::chunk_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned int *)d_counts.p,
+                               (unsigned int *)d_chunk_out.p, hdr_dev, l, (unsigned int)cap);
+            hipLaunchKernelGGL(rptb::sat_compact_kernel, dim3((unsigned int)chunks_l), dim3(256), 0, ctx->stream, (const int32_t *)list_l,
+                               (const rptb::ChildDesc *)d_children.p, (const rptb::BuildHeader *)hdr_dev, (const unsigned char *)d_flags.p,
+                               (const unsigned int *)d_chunk_out.p, list_next, (unsigned int)cap);
+            hipLaunchKernelGGL(rptb::next_nodes_kernel, dim3((unsigned int)((level_nodes[l + 1] + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const rptb::BNode *)nodes_l, (const rptb::ChildDesc *)d_children.p, (const unsigned int *)d_split.p,
+                               (const unsigned int *)d_chunk_out.p, (const rptb::BuildHeader *)hdr_dev, l, nodes_next);
+        }
         RPT_HIP(ctx, hipGetLastError());
-        std::vector<unsigned int> counts(n_chunks), chunk_out(n_chunks);
-        RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        RPT_HIP(ctx, hipMemcpy(counts.data(), d_counts.p, n_chunks * sizeof(unsigned int), hipMemcpyDeviceToHost));
-        unsigned long long total = 0;
-        for (unsigned int k = 0; k < n_chunks; k++) {
-            chunk_out[k] = (unsigned int)total;
-            total += counts[k];
+        lap("submit");
+        RPT_HIP(ctx, hipMemcpyAsync(&hdr, hdr_dev, sizeof hdr, hipMemcpyDeviceToHost, ctx->stream));
+        RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));             // the only wait of the build
+        lap("wait");
+        if (hdr.overflow) {
+            if (attempt >= 3) return fail(ctx, RPT_ERR_NOMEM, "rpt_build_octree: triangle lists keep outgrowing their buffers");
+            cap *= 4;
+            continue;
         }
-        if (total > 0x7fffffffull) return fail(ctx, RPT_ERR_NOMEM, "rpt_build_octree: triangle lists exceed 2^31 entries");
-        std::vector<int32_t> next_list((size_t)total);
-        if (total) {
-            RPT_HIP(ctx, hipMalloc(&d_next.p, (size_t)total * sizeof(int32_t)));
-            RPT_HIP(ctx, hipMemcpy(d_chunk_out.p, chunk_out.data(), n_chunks * sizeof(unsigned int), hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(rptb::sat_compact_kernel, dim3(n_chunks), dim3(256), 0, ctx->stream, (const int32_t *)d_list.p,
-                               (const rptb::ChildDesc *)d_children.p, (const unsigned int *)d_chunk_child.p,
-                               (const unsigned char *)d_flags.p, (const unsigned int *)d_chunk_out.p, (int32_t *)d_next.p, n_chunks);
-            RPT_HIP(ctx, hipGetLastError());
-            RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            RPT_HIP(ctx, hipMemcpy(next_list.data(), d_next.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost));
+        // read the levels back: nodes and lists of every level that has nodes
+        levels.clear();
+        lists.clear();
+        for (int l = 0; l <= max_depth && hdr.n_nodes[l] > 0; l++) {
+            if (hdr.n_nodes[l] > level_nodes[l] || hdr.list_len[l] > cap) return fail(ctx, RPT_ERR_DEVICE, "rpt_build_octree: inconsistent level sizes");
+            std::vector<rptb::BNode> dev_nodes(hdr.n_nodes[l]);
+            RPT_HIP(ctx, hipMemcpy(dev_nodes.data(), nodes_dev + node_offset[l], dev_nodes.size() * sizeof(rptb::BNode), hipMemcpyDeviceToHost));
+            std::vector<BuildNode> nodes(dev_nodes.size());
+            for (size_t i = 0; i < nodes.size(); i++) {
+                const rptb::BNode &d = dev_nodes[i];
+                BuildNode &b = nodes[i];
+                for (int k = 0; k < 3; k++) { b.mn[k] = d.mn[k]; b.mx[k] = d.mx[k]; }
+                b.list_begin = d.list_begin; b.list_count = d.list_count;
+                b.min_tris = d.min_tris; b.depth = d.depth; b.first_child = d.first_child; b.valence = d.valence;
+                if ((size_t)d.list_begin + d.list_count > hdr.list_len[l] || (d.first_child >= 0 && (l == max_depth || (size_t)d.first_child + 8 > hdr.n_nodes[l + 1])))
+                    return fail(ctx, RPT_ERR_DEVICE, "rpt_build_octree: inconsistent node record");
+            }
+            std::vector<int32_t> list(hdr.list_len[l]);
+            if (!list.empty())
+                RPT_HIP(ctx, hipMemcpy(list.data(), lists_dev + (size_t)l * cap, list.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            levels.push_back(std::move(nodes));
+            lists.push_back(std::move(list));
         }
-        // next level's nodes: the children, their lists consecutive in child order
-        std::vector<BuildNode> next_nodes(children.size());
-        size_t parent_of_child = 0;
-        std::vector<int> parent_index(children.size());
-        for (size_t pi = 0; pi < nodes.size(); pi++)
-            if (nodes[pi].first_child >= 0)
-                for (int k = 0; k < 8; k++) parent_index[(size_t)nodes[pi].first_child + k] = (int)pi;
-        (void)parent_of_child;
-        for (size_t c = 0; c < children.size(); c++) {
-            BuildNode &b = next_nodes[c];
-            b.mn[0] = children[c].minx; b.mn[1] = children[c].miny; b.mn[2] = children[c].minz;
-            b.mx[0] = children[c].maxx; b.mx[1] = children[c].maxy; b.mx[2] = children[c].maxz;
-            const unsigned int k0 = children[c].chunk_base, k1 = c + 1 < children.size() ? children[c + 1].chunk_base : n_chunks;
-            b.list_begin = chunk_out[k0];
-            unsigned int cnt = 0;
-            for (unsigned int k = k0; k < k1; k++) cnt += counts[k];
-            b.list_count = cnt;
-            b.min_tris = nodes[parent_index[c]].valence;
-            b.depth = nodes[parent_index[c]].depth - 1;
-        }
-        levels.push_back(std::move(next_nodes));
-        lists.push_back(std::move(next_list));
+        lap("readback");
+        break;
     }
+    lap("free");
 
     // the reference's numbering: a node's eight children and their lists are appended when the node is split,
     // and the children are then visited depth first (Octree.cpp:191-246)
     std::vector<rpt_octree> out_nodes;
     std::vector<int32_t> out_tris;
+    {
+        size_t n_nodes_all = 0, n_entries_all = 0;
+        for (size_t l = 0; l < levels.size(); l++) { n_nodes_all += levels[l].size(); n_entries_all += lists[l].size(); }
+        out_nodes.reserve(n_nodes_all);
+        out_tris.reserve(n_entries_all);
+    }
     auto make_node = [&](const BuildNode &b, const std::vector<int32_t> &list) {
         rpt_octree o;
         std::memset(&o, 0, sizeof o);
@@ -1206,6 +1219,7 @@ extern "C" int rpt_build_octree(rpt_ctx *ctx, const rpt_float3 *vertices, size_t
     };
     emit(0, 0, 0);
 
+    lap("emit");
     rpt_octree *nodes_host = (rpt_octree *)std::malloc(out_nodes.size() * sizeof(rpt_octree));
     int32_t *tris_host = (int32_t *)std::malloc((out_tris.size() ? out_tris.size() : 1) * sizeof(int32_t));
     if (!nodes_host || !tris_host) {

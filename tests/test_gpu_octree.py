@@ -59,3 +59,13 @@ def test_gpu_octree_dense_mesh_and_render(renderer, tmp_path):
     assert a["octrees"].size // 96 == 38361 and a["octreeTris"].size == 790266
     assert np.array_equal(a["octrees"], b["octrees"]) and np.array_equal(a["octreeTris"], b["octreeTris"])
     print(f"octree build, 79 488 triangles: host {t_cpu*1e3:.0f} ms (incl. OBJ parse), device path {t_gpu*1e3:.0f} ms")
+
+
+def test_gpu_octree_repeats_the_build_when_a_list_outgrows_its_buffer(renderer, monkeypatch):
+    """The build is one submission with list buffers of a fixed capacity; a level that outgrows it raises a flag in the
+    device-side header (nothing is written out of bounds) and the host repeats the build with four times the capacity.
+    Started at the smallest capacity possible (the root's own list), bunny.obj needs two repeats."""
+    monkeypatch.setenv("RPT_OCTREE_LIST_CAP", "1")
+    cpu, gpu, _, _ = build_both(renderer, ["Models/bunny.obj"])
+    a, b = cpu.buffers(), gpu.buffers()
+    assert np.array_equal(a["octrees"], b["octrees"]) and np.array_equal(a["octreeTris"], b["octreeTris"])
