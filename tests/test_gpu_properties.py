@@ -454,6 +454,33 @@ def test_bench_exchange_path_over_rccl_with_one_rank(tmp_path, split):
         assert cal["frame_ms_one_rank"] > 0 and cal["gather_base_ms"] >= 0
 
 
+@pytest.mark.parametrize("n,split,gather", [(2, "auto", "plane3"), (2, "equal", "plane3"), (2, "4", "plane3"), (2, "equal", "full16"),
+                                            (4, "equal", "plane3"), (3, "2", "plane3")])
+def test_bench_several_ranks_on_one_gpu_over_gloo(n, split, gather):
+    """`python bench.py --gpus N` BARE (it starts its own ranks) with RPT_BENCH_BACKEND=gloo, all ranks on this box's one GPU
+    (RCCL refuses two ranks per device; gloo does not care): N real processes, each with its own contexts, streams and events,
+    a real cross-process gather per batch of frames, the max-over-ranks timing, the calibration's collectives — everything of
+    the N > 1 path except RCCL itself and the wires.  Camera clock running; rank 0's framebuffer is checked against the oracle."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {**os.environ, "RPT_BENCH_BACKEND": "gloo", "RPT_BENCH_ANIMATE": "1", "RPT_SPLIT": split}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "14", "--warmup", "2", "--workload", "shadows",
+           "--width", "1280", "--height", "720", "--no-cpu-baseline", "--check", "--gather", gather]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == n and out["comm"] == {"backend": "gloo", "world_size": n, "ranks_in_group": n}
+    assert out["check"] == "framebuffer rows identical to the oracle", out["check"]
+    if split == "equal":
+        assert "tile k -> rank k mod N" in out["config"]["sharding"]
+    elif split == "auto":
+        assert out["config"]["split_calibration"]["tried_ms_per_frame"]
+    else:
+        assert out["config"]["sharding"].startswith("weighted")
+
+
 def test_16k_frame_structure_and_sampled_rows(renderer):
     """A 15360x8640 frame (132.7 M pixels, 2.1 GB of framebuffer; four times BASELINE's largest): every pixel's
     (x, y) floats checked on the device, and row bands through sky, silhouette and mesh compared with the oracle."""
