@@ -63,6 +63,34 @@ struct alignas(16) DObj {
 static_assert(sizeof(DObj) == 96, "DObj");
 
 struct KernelArgs {
+    // ---- the first 64 bytes are everything a wave that hits nothing needs (its cull and its store): one scalar load at the top
+    // of the kernel instead of one per place of first use (each is a dependent round trip in a wave that lives a microsecond)
+    // per-object image-plane rectangles (rpt_screen_bounds.hpp), tested lane-parallel by each wavefront (V >= 20)
+    const float4 *rects;                     // [2 * object_count] per object: u0, v0, u1, v1 on the plane z = 0.5, then the
+                                             // diagonal slabs p_lo, p_hi (u + v) and m_lo, m_hi (u - v)
+    rpt_pixel *out16;        // 16 B/pixel framebuffer (full frame addressing) or null
+    uint32_t *plane;         // compact 4 B/pixel colour plane (local tile addressing) or null
+    float *debug_rgb;        // 3 floats/pixel, full frame addressing, or null
+    int object_count;
+    int width, height;
+    int diagonals;                           // some object has diagonal slabs and the frame lies inside their window
+    float inv_width, inv_height;             // 1/width, 1/height (for the cull only: approximate is fine there)
+    float aspect;            // (float)width / (float)height
+    uint32_t bg_packed;      // the packed R,G,B,1 word of a miss pixel
+    // ---- second line: tile addressing, dispatch order, the rest of the scalars
+    int first_tile, tile_step;      // local tile t holds global tile (t >> run_log2) * tile_step + first_tile + (t & (run - 1))
+    int run_log2;                   // run = 1 << run_log2 consecutive tiles per period of tile_step tiles (rpt_set_tile_pattern)
+    int interval;
+    // dispatch order (V == 23): the strips [first_sx, first_sx + first_w) x [first_ty, first_ty + first_h) — where the meshes
+    // are, i.e. where the frame's longest waves live — are handed out FIRST, the rest in natural order; first_w = 0: off
+    int first_sx, first_ty, first_w, first_h;
+    float bg_mapped[3];      // min(hable(background)/hable(white_point), 1): what every miss pixel maps to
+    float ambient;
+    float hable_wp[3];       // hable(white_point), host-computed
+    // per-tile object masks: 8x8-pixel tiles of this context's rows, classified once per frame by rpt_tile_bin_kernel
+    int tiles_x, n_tiles;                    // tiles per row, tiles in this context's rows
+    unsigned long long *tile_masks;          // [n_tiles] bit i = primary rays of the tile may hit object i (i < 64)
+    // ---- the scene
     const DNode *dnodes;
     const DTri *dtris;
     const DObj *dobjs;
@@ -75,33 +103,9 @@ struct KernelArgs {
     const int32_t *octreeTris;
     const uint8_t *textures;
     long long texture_bytes;
-    rpt_pixel *out16;        // 16 B/pixel framebuffer (full frame addressing) or null
-    uint32_t *plane;         // compact 4 B/pixel colour plane (local tile addressing) or null
-    float *debug_rgb;        // 3 floats/pixel, full frame addressing, or null
     unsigned long long *wave_times; // diagnostic build only (variant 11): ten words per wave, {start, end} of s_memrealtime (100 MHz) + loop accounting
     unsigned long long *counters;   // diagnostic builds only (variant 7): [0..2] lane-level leaf/tri/descent
                                     // iterations, [3..5] the same counted once per executing wave
-    float hable_wp[3];       // hable(white_point), host-computed
-    float bg_mapped[3];      // min(hable(background)/hable(white_point), 1): what every miss pixel maps to
-    uint32_t bg_packed;      // its packed R,G,B,1 word
-    float ambient;
-    float aspect;            // (float)width / (float)height
-    int object_count;
-    int width, height;
-    int interval;
-    int first_tile, tile_step;      // local tile t holds global tile (t >> run_log2) * tile_step + first_tile + (t & (run - 1))
-    int run_log2;                   // run = 1 << run_log2 consecutive tiles per period of tile_step tiles (rpt_set_tile_pattern)
-    // per-tile object masks: 8x8-pixel tiles of this context's rows, classified once per frame by rpt_tile_bin_kernel
-    int tiles_x, n_tiles;                    // tiles per row, tiles in this context's rows
-    unsigned long long *tile_masks;          // [n_tiles] bit i = primary rays of the tile may hit object i (i < 64)
-    // per-object image-plane rectangles (rpt_screen_bounds.hpp), tested lane-parallel by each wavefront (V >= 20)
-    const float4 *rects;                     // [2 * object_count] per object: u0, v0, u1, v1 on the plane z = 0.5, then the
-                                             // diagonal slabs p_lo, p_hi (u + v) and m_lo, m_hi (u - v)
-    float inv_width, inv_height;             // 1/width, 1/height (for the cull only: approximate is fine there)
-    int diagonals;                           // some object has diagonal slabs and the frame lies inside their window
-    // dispatch order (V == 23): the strips [first_sx, first_sx + first_w) x [first_ty, first_ty + first_h) — where the meshes
-    // are, i.e. where the frame's longest waves live — are handed out FIRST, the rest in natural order; first_w = 0: off
-    int first_sx, first_ty, first_w, first_h;
 };
 
 struct Hit {                 // opencl_kernel.cl:38-44
@@ -766,10 +770,11 @@ RPT_DEV void store_pixel(void *out16, size_t id, uint32_t x, uint32_t y, uint32_
 
 RPT_DEV unsigned long long wave_object_mask(const KernelArgs &a, int tile_x0, int tile_y0) {
     const int lane = threadIdx.x & 63;
-    // one 16-B load per lane, issued unconditionally (lanes beyond the object count re-read rectangle 0: always a valid
-    // address when there is any object), and four compares without branches: one memory round trip, no divergence
+    // one 16-B load per lane, issued unconditionally (lanes beyond the object count re-read rectangle 0), and four compares
+    // without branches: one memory round trip, no divergence.  No early return for a scene without objects either: the buffer
+    // behind `rects` always holds at least one record's worth of bytes (rpt_api.hip: reserve), and a branch here would put the
+    // loads of `rects` and of the reciprocals behind it — one more dependent round trip in every wave.
     const int n = a.object_count;
-    if (n <= 0) return 0ull;                // a scene without objects has no records to read (wave-uniform)
     const int slot = (lane < n) ? lane : 0;
     const float4 r = a.rects[2 * slot];
     const float iw = a.inv_width, ih = a.inv_height;
@@ -822,7 +827,8 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
     if (x_coord >= a.width || y_coord >= a.height) return;   // the reference has no guard (UB)
 
     f3 color;
-    f3 mapped = mk3(a.bg_mapped[0], a.bg_mapped[1], a.bg_mapped[2]);
+    f3 mapped = mk3(0.0f, 0.0f, 0.0f);
+    bool traced = false;
     uint32_t packed = a.bg_packed;
     if (V == 10) {   // per-tile object mask of the prepass
         const int tile = __builtin_amdgcn_readfirstlane(tile_row * a.tiles_x + (int)blockIdx.x * 4 + wave);
@@ -831,7 +837,10 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
     const bool masked = V == 10 || V >= 20;
     if (!masked || object_mask != 0 || a.object_count > 64) {
         const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);
-        if (trace<V>(a, camdir, object_mask, color)) packed = tonemap_pack(a, color, mapped);
+        if (trace<V>(a, camdir, object_mask, color)) {
+            packed = tonemap_pack(a, color, mapped);
+            traced = true;
+        }
     }
 
     const size_t id = (size_t)y_coord * a.width + x_coord;
@@ -845,6 +854,7 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
     }
     if (a.plane) __builtin_nontemporal_store(packed, a.plane + (size_t)local_row * a.width + x_coord);
     if (a.debug_rgb) {
+        if (!traced) mapped = mk3(a.bg_mapped[0], a.bg_mapped[1], a.bg_mapped[2]);      // (read here only: a miss pixel's store needs nothing beyond the first line of the arguments)
         a.debug_rgb[3 * id + 0] = mapped.x;
         a.debug_rgb[3 * id + 1] = mapped.y;
         a.debug_rgb[3 * id + 2] = mapped.z;
