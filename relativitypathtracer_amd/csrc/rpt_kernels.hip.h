@@ -852,6 +852,7 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
         px.w = 0u;
         store_pixel(a.out16, id, px.x, px.y, px.z, px.w);
     }
+    // (the 4-byte plane likewise: measured against the default policy on a rank's share of the frame, bunny 4K 0.0581 -> 0.0566 ms, shadows the same)
     if (a.plane) __builtin_nontemporal_store(packed, a.plane + (size_t)local_row * a.width + x_coord);
     if (a.debug_rgb) {
         if (!traced) mapped = mk3(a.bg_mapped[0], a.bg_mapped[1], a.bg_mapped[2]);      // (read here only: a miss pixel's store needs nothing beyond the first line of the arguments)
