@@ -305,15 +305,143 @@ struct Accum {
     }
 };
 
+// One outline curve (a box edge, a sphere's rim), sampled ADAPTIVELY.  The curve is given by a parameter t -> object-space
+// direction; how the camera sees it is anything but uniform in t — an edge that passes close to the camera, or any curve
+// under aberration, can put half the screen between two neighbouring samples of a uniform grid (found by the extreme-scene
+// soak: a 10 x 2.5 x 12 cube at 0.9c next to a camera at 0.5c, eight uniform segments per edge, hits 0.17 outside the
+// diagonal bounds).  So the samples are placed where the IMAGE needs them: an interval is halved while its midpoint lies
+// off the chord by more than 3 `tol` (tol = a quarter of the margin the bounds get; once the midpoint is in, a quarter of that
+// deviation is what remains), while its two halves differ in length by more
+// than 3 : 1 (the parameter runs unevenly: the far half hides a bulge), while a chord is longer than a quarter of the screen
+// height, or — down to 1/16 of a base interval — while any of its three samples lies behind the clip cone (crossing() then
+// bisects where the side changes) — except for stretches wholly outside three screen heights, which can only move sides of the bounds that are off
+// the screen anyway.  The samples come out in curve order for Accum's polyline logic.
+struct Curve {
+    struct Sample { D3 u, nd; bool front; double pu, pv; };
+    static constexpr int CAP = 320, MAX_DEPTH = 6;
+    Sample s[CAP];
+    int n = 0;
+    bool failed = false, clipped = false;
+    double tol = 1.0e-3;
+
+    template <class Param>
+    Sample eval(Accum &acc, Param &at, double t, const D3 *known_u, const D3 *known_nd) {
+        Sample r;
+        r.u = known_u ? *known_u : at(t);
+        r.front = false;
+        r.pu = r.pv = 0.0;
+        if (known_nd) { r.nd = *known_nd; acc.classify(r.nd, r.front); }
+        else if (!acc.map_sample(r.u, r.nd, r.front, false)) { failed = true; r.nd = D3{0, 0, 1}; }
+        if (r.front) { const double iz = 0.5 / r.nd.z; r.pu = r.nd.x * iz; r.pv = r.nd.y * iz; }
+        clipped = clipped || !r.front;
+        return r;
+    }
+    void push(const Sample &x) {
+        if (n < CAP) s[n++] = x; else failed = true;
+    }
+    bool needs_more(const Sample &a, const Sample &m, const Sample &b, int depth) const {
+        // a stretch that is not wholly in front of the clip cone is looked at in sixteenths of the base interval: where it comes
+        // to the front (crossing() then bisects), and whether a stretch between two samples behind the camera does at all
+        if (!(a.front && m.front && b.front)) return depth < 4;
+        const double W = 3.0;       // beyond three screen heights nothing on the screen can depend on the curve's exact course
+        if ((a.pu > W && m.pu > W && b.pu > W) || (a.pu < -W && m.pu < -W && b.pu < -W) || (a.pv > W && m.pv > W && b.pv > W) ||
+            (a.pv < -W && m.pv < -W && b.pv < -W)) return false;
+        // (squared lengths throughout: no square roots.)  With the midpoint inserted, what is left of a smooth arc's deviation is
+        // about a quarter of what the midpoint showed: the interval is good once that is within tol, i.e. dev <= 3 tol
+        const double cx = b.pu - a.pu, cy = b.pv - a.pv, cl2 = cx * cx + cy * cy;
+        const double ax = m.pu - a.pu, ay = m.pv - a.pv, bx = b.pu - m.pu, by = b.pv - m.pv;
+        const double la2 = ax * ax + ay * ay, lb2 = bx * bx + by * by;
+        const double area = cx * ay - cy * ax;                          // |area| / |chord| = the midpoint's distance from the chord
+        const double lmax2 = std::max(la2, lb2), lmin2 = std::min(la2, lb2);
+        // ... for a GENTLE arc, that is (halves within 1.5 : 1, midpoint within 8 % of the chord's length off it: curvature about
+        // even); anything else is held to tol itself, i.e. its halves get looked at
+        const bool gentle = lmax2 <= 2.25 * lmin2 && area * area <= 0.0064 * cl2 * cl2;
+        const double t3 = gentle ? 3.0 * tol : tol;
+        if (!(cl2 > 0.0 ? area * area <= t3 * t3 * cl2 : la2 <= t3 * t3)) return true;      // (NaN refines too)
+        if (lmax2 > 9.0 * lmin2 + 4.0 * tol * tol) return true;         // halves more uneven than 3 : 1
+        return lmax2 > 0.0625;                                           // a chord longer than a quarter of the screen height
+    }
+    template <class Param>
+    void refine(Accum &acc, Param &at, const Sample &a, double ta, const Sample &b, double tb, int depth) {
+        if (failed) return;
+        const double tm = 0.5 * (ta + tb);
+        const Sample m = eval(acc, at, tm, nullptr, nullptr);
+        const bool more = !failed && depth < MAX_DEPTH && needs_more(a, m, b, depth);
+        if (more) refine(acc, at, a, ta, m, tm, depth + 1);
+        push(m);
+        if (more) refine(acc, at, m, tm, b, tb, depth + 1);
+    }
+    // Samples the curve over `intervals` (<= 16) base intervals of t in [0, 1]; first/last: known end points (or null).  The
+    // tolerance is a quarter of the margin finish() will add: rel_margin of the on-screen extent — `extent` if the caller knows
+    // it (a box: of all its corners), else that of the base samples — plus 1e-3.
+    template <class Param>
+    void sample(Accum &acc, Param at, int intervals, bool adaptive, const D3 *u0, const D3 *nd0, const D3 *u1, const D3 *nd1,
+                double rel_margin, double extent, double forced_tol = -1.0) {
+        n = 0;
+        failed = false;
+        clipped = false;
+        Sample base[17];
+        if (intervals > 16) intervals = 16;
+        for (int k = 0; k <= intervals && !failed; k++)
+            base[k] = k == 0 ? eval(acc, at, 0.0, u0, nd0) : (k == intervals ? eval(acc, at, 1.0, u1, nd1) : eval(acc, at, (double)k / intervals, nullptr, nullptr));
+        if (!failed && adaptive) {
+            if (!(extent > 0.0)) {
+                double a0 = 1e300, a1 = -1e300, b0 = 1e300, b1 = -1e300;
+                for (int k = 0; k <= intervals; k++) {
+                    if (!base[k].front) continue;
+                    const double pu = std::max(-1.25, std::min(1.25, base[k].pu)), pv = std::max(-0.55, std::min(0.55, base[k].pv));
+                    a0 = std::min(a0, pu); a1 = std::max(a1, pu); b0 = std::min(b0, pv); b1 = std::max(b1, pv);
+                }
+                extent = a1 >= a0 ? std::min(a1 - a0, b1 - b0) : 0.0;        // the smaller one: each side's margin is relative to its own extent
+            }
+            tol = forced_tol > 0.0 ? forced_tol : std::max(2.5e-4, 0.25 * (rel_margin * extent + 1.0e-3));
+        }
+        for (int k = 0; k <= intervals && !failed; k++) {
+            if (k > 0 && adaptive) refine(acc, at, base[k - 1], (double)(k - 1) / intervals, base[k], (double)k / intervals, 0);
+            push(base[k]);
+        }
+        if (failed) acc.failed = true;
+    }
+    // hands the samples to Accum as ONE polyline (pen up first), crossings located where the side changes
+    void draw(Accum &acc, bool closed) {
+        if (acc.failed || n == 0) return;
+        acc.pen_up();
+        for (int k = 0; k < n && !acc.failed; k++) {
+            if (k > 0 && s[k].front != s[k - 1].front) acc.crossing(s[k - 1].u, s[k].u, s[k - 1].front);
+            if (acc.failed) break;
+            acc.feed(s[k].nd, s[k].front);
+        }
+        (void)closed;
+    }
+};
+
+// margins relative to the part of the box that can matter (screens reach |u| <= aspect/2, |v| <= 1/2; clipped curves
+// reach out to |u|, |v| ~ 25, which must not loosen the sides that lie on the screen; wider screens than 2.5 : 1 only
+// get a margin that is smaller relative to their width, and the 1e-3 floor)
+inline double clamp_u(double x) { return std::max(-1.25, std::min(1.25, x)); }     // screens up to 2.5 : 1
+inline double clamp_v(double x) { return std::max(-0.55, std::min(0.55, x)); }
+inline void margins(const Accum &acc, double rel_margin, double &mu, double &mv) {
+    mu = rel_margin * (clamp_u(acc.u1) - clamp_u(acc.u0)) + 1.0e-3;
+    mv = rel_margin * (clamp_v(acc.v1) - clamp_v(acc.v0)) + 1.0e-3;
+}
+// The adaptive sampling worked to a tolerance derived from an ESTIMATE of the on-screen extent; the margins come from the extent
+// that was found.  If they turned out smaller than assumed (a large object of which a sliver is on the screen), the outline has to
+// be followed again, to a quarter of the smaller margin.  Returns that tolerance, or 0 if the first pass was good enough.
+inline double second_pass_tolerance(const Accum &acc, double rel_margin, double tol_used) {
+    if (acc.failed || !acc.any_front) return 0.0;
+    double mu, mv;
+    margins(acc, rel_margin, mu, mv);
+    const double need = 0.25 * std::min(mu, mv);
+    return need < 0.999 * tol_used ? std::max(1.0e-4, need) : 0.0;
+}
+
 inline Rect finish(const Accum &acc, double rel_margin) {
     if (acc.failed) return full_rect();
     if (!acc.any_front) return acc.any_near_behind ? full_rect() : empty_rect();      // wholly (and well) behind the camera
-    // margins relative to the part of the box that can matter (screens reach |u| <= aspect/2, |v| <= 1/2; clipped curves
-    // reach out to |u|, |v| ~ 25, which must not loosen the sides that lie on the screen; wider screens than 2.5 : 1 only
-    // get a margin that is smaller relative to their width, and the 1e-3 floor)
-    auto clu = [](double x) { return std::max(-1.25, std::min(1.25, x)); };     // screens up to 2.5 : 1
-    auto clv = [](double x) { return std::max(-0.55, std::min(0.55, x)); };
-    const double mu = rel_margin * (clu(acc.u1) - clu(acc.u0)) + 1.0e-3, mv = rel_margin * (clv(acc.v1) - clv(acc.v0)) + 1.0e-3;
+    auto clu = [](double x) { return clamp_u(x); };
+    auto clv = [](double x) { return clamp_v(x); };
+    double mu, mv;
+    margins(acc, rel_margin, mu, mv);
     const double r[4] = {acc.u0 - mu, acc.v0 - mv, acc.u1 + mu, acc.v1 + mv};
     for (double x : r) if (!std::isfinite(x)) return full_rect();
     auto clampf = [](double x) { return (float)std::max(-3.0e38, std::min(3.0e38, x)); };
@@ -387,8 +515,6 @@ inline Rect box_rect(const rpt_object &o, int interval, const double bmin[3], co
         seen_lo[a] = p[a] < lo[a] - tol ? 1 : (p[a] > lo[a] + tol ? -1 : 0);
         seen_hi[a] = p[a] > hi[a] + tol ? 1 : (p[a] < hi[a] - tol ? -1 : 0);
     }
-    int S = m.linear ? 1 : 8;                 // segments per edge: straight edges stay straight under a linear map; under
-                                              // aberration they become conic arcs: 8 segments, 16 when the outline is clipped
     // the eight corners are mapped once (corner k: bit 0/1/2 = x/y/z at hi); the first and the last one are pushed
     // through F again, which is where a wrong inverse would show
     D3 cu[8], cnd[8];
@@ -409,29 +535,27 @@ inline Rect box_rect(const rpt_object &o, int interval, const double bmin[3], co
         m.tol = std::min(1.0e-4, 5.0e-3 * ang);
         if (!m.verify(cu[0], cnd[0]) || !m.verify(cu[7], cnd[7])) return full_rect();
     }
-    if (!m.linear) {
-        // How far an aberrated edge bends away from its chord: an edge that spans the angle theta (seen from the camera, in the
-        // object's rest frame) comes out as an arc whose sagitta is about theta * gamma * beta / 8 of its length (gamma * beta
-        // of the relative motion = sqrt(L00^2 - 1)); with S segments the worst one keeps 1 / S^2 of that.  S is chosen to keep
-        // it under half a percent — a fifth of the margin the box gets — between 2 and 8; a clipped outline gets 16 below.
-        double cmin = 1.0;
-        D3 rc = m.to_rest(sub(D3{0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])}, oc));
-        const double lrc = len(rc);
-        for (int k = 0; k < 8 && lrc > 0.0; k++) {
-            const D3 r = m.to_rest(cu[k]);
-            const double lr = len(r);
-            if (lr > 0.0) cmin = std::min(cmin, dot(r, rc) / (lr * lrc));
+    // the on-screen extent of the box's corners: what the margin of the bounds — and with it the tolerance of the adaptive
+    // sampling — is relative to (finish())
+    const double rel_margin = m.linear ? 0.002 : 0.025;
+    double extent = 0.0;
+    {
+        double a0 = 1e300, a1 = -1e300, b0 = 1e300, b1 = -1e300;
+        for (int k = 0; k < 8; k++) {
+            if (!Accum::is_front(cnd[k])) continue;
+            const double iz = 0.5 / cnd[k].z, pu = std::max(-1.25, std::min(1.25, cnd[k].x * iz)), pv = std::max(-0.55, std::min(0.55, cnd[k].y * iz));
+            a0 = std::min(a0, pu); a1 = std::max(a1, pu); b0 = std::min(b0, pv); b1 = std::max(b1, pv);
         }
-        const double theta = 2.0 * std::acos(std::max(-1.0, std::min(1.0, cmin)));
-        const double g = m.L[0][0], gb = g > 1.0 ? std::sqrt(g * g - 1.0) : 0.0;
-        const double want = std::sqrt(std::max(0.0, theta * gb / 8.0 / 0.005));
-        S = want <= 2.0 ? 2 : (want <= 4.0 ? 4 : 8);
-        for (int k = 0; k < 8; k++)
-            if (!Accum::is_front(cnd[k])) S = 16;      // a corner behind the clip cone: the outline is clipped, sample finely at once
+        extent = a1 >= a0 ? std::min(a1 - a0, b1 - b0) : 0.0;            // the smaller one: each side's margin is relative to its own extent
+        if (!(extent > 0.0)) extent = 1.0e-9;      // (no corner in front, or a box seen edge-on: the 1e-3 floor of the margin sets the tolerance)
     }
-    Accum acc(m);
+    double blo[3], bhi[3];
+    for (int a = 0; a < 3; a++) { const double g = 0.05 * (hi[a] - lo[a]) + 1.0e-4; blo[a] = lo[a] - g; bhi[a] = hi[a] + g; }
+    auto inside_box = [&](D3 d) { return !finite3(d) || ray_meets_box(p, d, blo, bhi); };
+    static thread_local Curve curve;          // (320 samples: kept off the stack of every call)
+    double tol_used = 0.0;
+    auto outline = [&](Accum &acc, double forced_tol) {
     bool clipped = false;
-resample:
     for (int axis = 0; axis < 3 && !acc.failed; axis++) {
         const int b = (axis + 1) % 3, c = (axis + 2) % 3;
         for (int corner = 0; corner < 4 && !acc.failed; corner++) {
@@ -440,36 +564,23 @@ resample:
             double q[3];
             q[b] = (corner & 1) ? hi[b] : lo[b];
             q[c] = (corner & 2) ? hi[c] : lo[c];
-            D3 prev_u{};
-            bool prev_front = false;
             const int k_lo = ((corner & 1) ? (1 << b) : 0) | ((corner & 2) ? (1 << c) : 0), k_hi = k_lo | (1 << axis);
-            for (int j = 0; j <= S; j++) {
-                q[axis] = lo[axis] + (hi[axis] - lo[axis]) * ((double)j / S);
-                const D3 u = j == 0 ? cu[k_lo] : (j == S ? cu[k_hi] : sub(D3{q[0], q[1], q[2]}, oc));
-                D3 nd;
-                bool front = false;
-                if (j == 0 || j == S) acc.classify(nd = (j == 0 ? cnd[k_lo] : cnd[k_hi]), front);
-                else if (!acc.map_sample(u, nd, front, false)) break;
-                clipped = clipped || !front;
-                if (j == 0) acc.pen_up();                       // every edge is a polyline of its own
-                else if (front != prev_front) acc.crossing(prev_u, u, prev_front);
-                if (acc.failed) break;
-                acc.feed(nd, front);
-                prev_u = u; prev_front = front;
-            }
+            auto at = [&](double t) {
+                double r[3] = {q[0], q[1], q[2]};
+                r[axis] = lo[axis] + (hi[axis] - lo[axis]) * t;
+                return sub(D3{r[0], r[1], r[2]}, oc);
+            };
+            // straight edges stay straight under a linear map: its two corners are the edge; under aberration an edge becomes a
+            // conic arc, followed adaptively from its two corners
+            curve.sample(acc, at, 1, !m.linear, &cu[k_lo], &cnd[k_lo], &cu[k_hi], &cnd[k_hi], rel_margin, extent, forced_tol);
+            tol_used = std::max(tol_used, curve.tol);
+            clipped = clipped || curve.clipped;
+            curve.draw(acc, false);                             // every edge is a polyline of its own
         }
     }
-    if (acc.failed) return full_rect();
-    if (clipped && !m.linear && S < 16) {      // an outline that runs off to the horizon bends hardest there: sample it again, finer
-        S = 16;
-        acc = Accum(m);
-        goto resample;
-    }
+    if (acc.failed) return;
     // the horizon: when the whole outline is in front of the camera only a region that wraps around behind the camera can
     // reach it (strong aberration can produce one; wraps_behind asks); always when the outline is clipped
-    double blo[3], bhi[3];
-    for (int a = 0; a < 3; a++) { const double g = 0.05 * (hi[a] - lo[a]) + 1.0e-4; blo[a] = lo[a] - g; bhi[a] = hi[a] + g; }
-    auto inside_box = [&](D3 d) { return !finite3(d) || ray_meets_box(p, d, blo, bhi); };
     if (!clipped) {
         // (a linear map keeps the cone of kept directions convex: with its whole outline in front of the camera it cannot
         // reach the horizon, so only aberrated outlines are asked)
@@ -478,7 +589,19 @@ resample:
         acc.horizon(32, inside_box);
     }
     if (acc.reaches_window_edge()) acc.window_corners(inside_box);
-    return finish(acc, m.linear ? 0.002 : 0.025);
+    };
+    Accum acc(m);
+    outline(acc, -1.0);
+    if (!m.linear) {
+        const double again = second_pass_tolerance(acc, rel_margin, tol_used);
+        if (again > 0.0) {
+            Accum finer(m);
+            tol_used = 0.0;
+            outline(finer, again);
+            acc = finer;
+        }
+    }
+    return finish(acc, rel_margin);
 }
 
 // Unit sphere at the object-space origin.
@@ -506,40 +629,46 @@ inline Rect sphere_rect(const rpt_object &o, int interval) {
     D3 e1 = cross(axis, helper);
     e1 = mul(e1, 1.0 / len(e1));
     const D3 e2 = cross(axis, e1);
-    const int K = m.linear ? 16 : 32;      // samples on the tangent cone's rim
-    Accum acc(m);
-    bool clipped = false;
-    D3 first_u{}, prev_u{}, first_nd{};
-    bool first_front = false, prev_front = false;
-    for (int k = 0; k < K && !acc.failed; k++) {
-        const double phi = 2.0 * M_PI * k / K;
-        const D3 u = add(mul(axis, ca), mul(add(mul(e1, std::cos(phi)), mul(e2, std::sin(phi))), sa));
-        D3 nd;
-        bool front = false;
-        if (!acc.map_sample(u, nd, front, (k & 7) == 0)) break;
-        clipped = clipped || !front;
-        if (k == 0) { first_u = u; first_front = front; first_nd = nd; }
-        else if (front != prev_front) acc.crossing(prev_u, u, prev_front);
-        if (acc.failed) break;
-        acc.feed(nd, front);
-        prev_u = u; prev_front = front;
-    }
-    if (!acc.failed) {                                          // close the rim
-        if (prev_front != first_front) acc.crossing(prev_u, first_u, prev_front);
-        if (!acc.failed) acc.feed(first_nd, first_front);
-    }
-    if (acc.failed) return full_rect();
+    // the rim of the tangent cone, followed adaptively from twelve base intervals (a circle seen under perspective or aberration
+    // is anything but uniformly parametrised by its own angle; an undistorted one is done with these and their midpoints)
+    auto at = [&](double t) {
+        const double phi = 2.0 * M_PI * t;
+        return add(mul(axis, ca), mul(add(mul(e1, std::cos(phi)), mul(e2, std::sin(phi))), sa));
+    };
+    static thread_local Curve curve;
+    const D3 u_first = at(0.0);
+    D3 nd_first;
+    if (!m.G_checked(u_first, nd_first)) return full_rect();
     const double cos_in = std::cos(std::min(1.5, std::asin(sa) * 1.05 + 0.01));      // the cone, a little wider
     auto inside_cone = [&](D3 d) {
         const double l = len(d);
         return !finite3(d) || !(l > 0.0) || dot(d, axis) >= cos_in * l;
     };
-    if (!clipped) {
-        if (!m.linear && acc.wraps_behind(inside_cone)) acc.horizon(32, inside_cone);
-    } else {
-        acc.horizon(32, inside_cone);
+    double tol_used = 0.0;
+    auto outline = [&](Accum &acc, double forced_tol) {
+        curve.sample(acc, at, 12, true, &u_first, &nd_first, &u_first, &nd_first, 0.04, 0.0, forced_tol);      // closed: ends where it began
+        tol_used = curve.tol;
+        const bool clipped = curve.clipped;
+        // every eighth sample is pushed through F again (a wrong inverse shows there too)
+        for (int k = 0; k < curve.n && !acc.failed; k += 8)
+            if (!m.verify(curve.s[k].u, curve.s[k].nd)) acc.failed = true;
+        curve.draw(acc, true);
+        if (acc.failed) return;
+        if (!clipped) {
+            if (!m.linear && acc.wraps_behind(inside_cone)) acc.horizon(32, inside_cone);
+        } else {
+            acc.horizon(32, inside_cone);
+        }
+        if (acc.reaches_window_edge()) acc.window_corners(inside_cone);
+    };
+    Accum acc(m);
+    outline(acc, -1.0);
+    const double again = second_pass_tolerance(acc, 0.04, tol_used);
+    if (again > 0.0) {
+        Accum finer(m);
+        outline(finer, again);
+        acc = finer;
     }
-    if (acc.reaches_window_edge()) acc.window_corners(inside_cone);
     return finish(acc, 0.04);
 }
 
