@@ -150,6 +150,30 @@ def test_rectangles_contain_every_hit_extreme_boosts(seed):
     check_scene(scene, 160, 90, f"extreme {seed}")
 
 
+@pytest.mark.parametrize("kind,seed", [("extreme", 28819), ("extreme", 7100), ("random", 1919)])
+def test_rectangles_contain_every_hit_cases_the_soak_runs_found(kind, seed):
+    """Three scenes that soak runs over 100 000 seeds found, each a different way of SAMPLING an outline too coarsely:
+    extreme 28819 — a 10 x 2.5 x 12 cube at 0.9c next to a camera at 0.5c (relative gamma 3.5, nothing extreme about it): one of its
+    edges passes so close that eight uniform segments put half the screen between two samples, and 296 pixels fell outside the
+    diagonal bounds; extreme 7100 — a large box of which only a sliver at the bottom of the screen is visible: margins are
+    relative to the on-screen extent, which was much smaller than the estimate the sampling tolerance came from; random 1919 —
+    an edge whose two corners and midpoint lie behind the camera while the stretch in between swings into view.  The outline is
+    now sampled adaptively in image space (Curve in rpt_screen_bounds.hpp)."""
+    if kind == "extreme":
+        from scene_fuzz import extreme_scene_text
+        rng = np.random.default_rng(550000 + seed)
+        scene = Scene()
+        scene.inputScene(extreme_scene_text(rng))
+        v = rng.normal(size=3)
+        v = v / np.linalg.norm(v) * rng.choice([0.0, 0.5, 0.9, 0.99, 0.999])
+        scene.set_camera(tuple(float(c) for c in v), float(rng.uniform(-5, 40)))
+        scene.update_objects()
+        for W, H in ((160, 90), (320, 184)):
+            check_scene(scene, W, H, f"extreme {seed} {W}x{H}")
+    else:
+        test_rectangles_contain_every_hit_random_scenes(seed)
+
+
 ADVERSARIAL = [
     # huge and tiny scales, a slab seen edge-on, a box the camera stands on, one it is inside of, a sphere it touches
     "Oc\n p0,0,8,0,0,1,0,1000,1000,0.001\n c1,1,1\nOs\n p0.5,0.2,3,0,0,1,0,0.0001,0.0001,0.0001\n c1,1,1\nA0.5\nR\n",
