@@ -314,11 +314,11 @@ struct Accum {
 // deviation is what remains), while its two halves differ in length by more
 // than 3 : 1 (the parameter runs unevenly: the far half hides a bulge), while a chord is longer than a quarter of the screen
 // height, or — down to 1/16 of a base interval — while any of its three samples lies behind the clip cone (crossing() then
-// bisects where the side changes) — except for stretches wholly outside three screen heights, which can only move sides of the bounds that are off
-// the screen anyway.  The samples come out in curve order for Accum's polyline logic.
+// bisects where the side changes); off the screen all of this is relative to the stretch's distance from the screen.  An interval that still wants halving at 1/512 of a base interval, or a curve of more than 640 samples,
+// makes the whole object's bounds the full plane.  The samples come out in curve order for Accum's polyline logic.
 struct Curve {
     struct Sample { D3 u, nd; bool front; double pu, pv; };
-    static constexpr int CAP = 320, MAX_DEPTH = 6;
+    static constexpr int CAP = 640, MAX_DEPTH = 9;
     Sample s[CAP];
     int n = 0;
     bool failed = false, clipped = false;
@@ -342,12 +342,37 @@ struct Curve {
     bool needs_more(const Sample &a, const Sample &m, const Sample &b, int depth) const {
         // a stretch that is not wholly in front of the clip cone is looked at in sixteenths of the base interval: where it comes
         // to the front (crossing() then bisects), and whether a stretch between two samples behind the camera does at all
-        if (!(a.front && m.front && b.front)) return depth < 4;
-        const double W = 3.0;       // beyond three screen heights nothing on the screen can depend on the curve's exact course
-        if ((a.pu > W && m.pu > W && b.pu > W) || (a.pu < -W && m.pu < -W && b.pu < -W) || (a.pv > W && m.pv > W && b.pv > W) ||
-            (a.pv < -W && m.pv < -W && b.pv < -W)) return false;
-        // (squared lengths throughout: no square roots.)  With the midpoint inserted, what is left of a smooth arc's deviation is
-        // about a quarter of what the midpoint showed: the interval is good once that is within tol, i.e. dev <= 3 tol
+        // ... and further wherever two neighbouring samples IN FRONT are still far apart on the image (the visible end of a stretch
+        // that leaves through the clip cone inside one sixteenth)
+        if (!(a.front && m.front && b.front)) {
+            if (depth < 4) return true;
+            auto off = [](const Sample &x) {
+                const double dx = std::max(0.0, std::fabs(x.pu) - DIAG_WINDOW_U), dy = std::max(0.0, std::fabs(x.pv) - DIAG_WINDOW_V);
+                return std::sqrt(dx * dx + dy * dy);
+            };
+            auto far_apart = [&](const Sample &x, const Sample &y) {
+                if (!(x.front && y.front)) return false;
+                const double lim = std::max(0.25, 0.5 * std::min(off(x), off(y))), dx = x.pu - y.pu, dy = x.pv - y.pv;
+                return dx * dx + dy * dy > lim * lim;
+            };
+            // ... and a sample in front next to one behind must itself be well outside the window: between the two the curve runs
+            // off to the clip cone, and the part of that run that crosses the window has to lie between samples that see it
+            auto leaves_unwatched = [&](const Sample &x, const Sample &y) { return x.front != y.front && off(x.front ? x : y) < 3.0; };
+            return far_apart(a, m) || far_apart(m, b) || leaves_unwatched(a, m) || leaves_unwatched(m, b);
+        }
+        // Off the screen the tolerance grows with the distance D of the three samples from the box |u| <= 2, |v| <= 0.55 (the window
+        // the diagonal bounds are taken in — a slab that touches the region out at u = 1.8 still cuts pixels at u = 0.5):
+        // what the bounds need from a stretch out there is only that it does not come in unnoticed, and a curve that runs off
+        // towards the horizon (image coordinates up to 25) cannot be followed to a fraction of a pixel all the way.  (A first
+        // version simply skipped stretches whose three samples lay beyond three screen heights on the same side — and lost an
+        // edge that swung from u = -3.8 in to u = -0.23 and back between two of them, under a relative gamma of 17.)
+        auto off_screen = [](const Sample &x) {
+            const double dx = std::max(0.0, std::fabs(x.pu) - DIAG_WINDOW_U), dy = std::max(0.0, std::fabs(x.pv) - DIAG_WINDOW_V);
+            return std::sqrt(dx * dx + dy * dy);
+        };
+        const double D = std::min(off_screen(a), std::min(off_screen(m), off_screen(b)));
+        // (squared lengths throughout.)  With the midpoint inserted, what is left of a smooth arc's deviation is about a quarter
+        // of what the midpoint showed: the interval is good once that is within tol, i.e. dev <= 3 tol ...
         const double cx = b.pu - a.pu, cy = b.pv - a.pv, cl2 = cx * cx + cy * cy;
         const double ax = m.pu - a.pu, ay = m.pv - a.pv, bx = b.pu - m.pu, by = b.pv - m.pv;
         const double la2 = ax * ax + ay * ay, lb2 = bx * bx + by * by;
@@ -356,17 +381,20 @@ struct Curve {
         // ... for a GENTLE arc, that is (halves within 1.5 : 1, midpoint within 8 % of the chord's length off it: curvature about
         // even); anything else is held to tol itself, i.e. its halves get looked at
         const bool gentle = lmax2 <= 2.25 * lmin2 && area * area <= 0.0064 * cl2 * cl2;
-        const double t3 = gentle ? 3.0 * tol : tol;
+        const double t3 = std::max(gentle ? 3.0 * tol : tol, 0.1 * D);
         if (!(cl2 > 0.0 ? area * area <= t3 * t3 * cl2 : la2 <= t3 * t3)) return true;      // (NaN refines too)
-        if (lmax2 > 9.0 * lmin2 + 4.0 * tol * tol) return true;         // halves more uneven than 3 : 1
-        return lmax2 > 0.0625;                                           // a chord longer than a quarter of the screen height
+        if (lmax2 > 9.0 * lmin2 + 4.0 * t3 * t3) return true;           // halves more uneven than 3 : 1
+        const double lmax = std::max(0.25, 0.5 * D);                     // a chord longer than a quarter of the screen height, or than half its distance
+        return lmax2 > lmax * lmax;
     }
     template <class Param>
     void refine(Accum &acc, Param &at, const Sample &a, double ta, const Sample &b, double tb, int depth) {
         if (failed) return;
         const double tm = 0.5 * (ta + tb);
         const Sample m = eval(acc, at, tm, nullptr, nullptr);
-        const bool more = !failed && depth < MAX_DEPTH && needs_more(a, m, b, depth);
+        const bool wants = !failed && needs_more(a, m, b, depth);
+        if (wants && depth >= MAX_DEPTH) failed = true;      // still not resolved at 1/512 of a base interval: no statement (full plane)
+        const bool more = wants && !failed;
         if (more) refine(acc, at, a, ta, m, tm, depth + 1);
         push(m);
         if (more) refine(acc, at, m, tm, b, tb, depth + 1);
@@ -552,7 +580,7 @@ inline Rect box_rect(const rpt_object &o, int interval, const double bmin[3], co
     double blo[3], bhi[3];
     for (int a = 0; a < 3; a++) { const double g = 0.05 * (hi[a] - lo[a]) + 1.0e-4; blo[a] = lo[a] - g; bhi[a] = hi[a] + g; }
     auto inside_box = [&](D3 d) { return !finite3(d) || ray_meets_box(p, d, blo, bhi); };
-    static thread_local Curve curve;          // (320 samples: kept off the stack of every call)
+    static thread_local Curve curve;          // (640 samples: kept off the stack of every call)
     double tol_used = 0.0;
     auto outline = [&](Accum &acc, double forced_tol) {
     bool clipped = false;

@@ -82,3 +82,41 @@ def extreme_scene_text(rng):
         lines.append("I")
     lines.append("R")
     return "\n".join(lines) + "\n"
+
+
+def close_scene_text(rng):
+    """Large boxes, slabs, rulers and spheres CLOSE to the camera (a few of their own sizes away, some enclosing it) at 0 .. 0.99c,
+    meshes among them, light propagation on or off: outlines that fill the screen, leave it, and pass near the camera — where the
+    mapping from an outline's own parameter to the image is least uniform (the regime of the soak's seed 28 819)."""
+    lines = ["MModels/cube.obj", "MModels/pear.obj"]
+    for k in range(int(rng.integers(1, 5))):
+        kind = rng.choice(["s", "c", "c", "m0", "m1"])
+        lines.append("O" + kind)
+        size = float(rng.choice([0.5, 2.0, 6.0, 15.0]))
+        shape = rng.choice(["cube", "slab", "ruler"])
+        sc = np.full(3, size) * rng.uniform(0.6, 1.4, size=3)
+        if shape == "slab":
+            sc[int(rng.integers(0, 3))] *= 0.02
+        elif shape == "ruler":
+            keep = int(rng.integers(0, 3))
+            for a in range(3):
+                if a != keep:
+                    sc[a] *= 0.03
+        direction = rng.normal(size=3)
+        direction[2] = abs(direction[2]) * rng.choice([1.0, 1.0, 1.0, -1.0])
+        pos = direction / np.linalg.norm(direction) * size * rng.uniform(0.3, 4.0)
+        ang = float(rng.uniform(-3, 3))
+        axis = rng.normal(size=3)
+        lines.append(" p" + ",".join(f"{v:.4f}" for v in [*pos, ang, *axis, *sc]))
+        lines.append(" c1,1,1")
+        if rng.random() < 0.3:
+            lines.append(" l1")
+        if rng.random() < 0.7:
+            v = rng.normal(size=3)
+            v = v / np.linalg.norm(v) * rng.choice([0.3, 0.7, 0.9, 0.97, 0.99])
+            lines.append(" v" + ",".join(f"{c:.6f}" for c in v))
+    lines.append("A0.5")
+    if rng.random() < 0.4:
+        lines.append("I")
+    lines.append("R")
+    return "\n".join(lines) + "\n"

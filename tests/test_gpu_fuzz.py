@@ -89,6 +89,37 @@ def test_extreme_scene(renderer, seed):
         assert np.array_equal(px["rgba"], opx["rgba"]), f"extreme seed {seed} variant {variant}: packed bytes differ\n{text}"
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RPT_CLOSE_FIRST", "0")), int(os.environ.get("RPT_CLOSE_LAST", "32"))))
+def test_close_scene(renderer, seed):
+    """scene_fuzz.close_scene_text: large boxes, slabs, rulers, spheres and meshes a few of their own sizes from the camera, at up to
+    0.99c — outlines that fill the screen and pass near the camera, the regime in which the screen bounds' outline sampling was
+    found too coarse three times (tests/test_screen_bounds.py).  Bit-identical to the oracle through all four kernels."""
+    from scene_fuzz import close_scene_text
+    rng = np.random.default_rng(770000 + seed)
+    text = close_scene_text(rng)
+    scene = Scene()
+    scene.inputScene(text)
+    v = rng.normal(size=3)
+    v = v / np.linalg.norm(v) * rng.choice([0.0, 0.3, 0.7, 0.9, 0.97])
+    scene.set_camera(tuple(float(c) for c in v), float(rng.uniform(-2, 6)))
+    scene.update_objects()
+    W, H = [(320, 184), (256, 144), (400, 160)][seed % 3]
+    opx, orgb, _ = oracle_ffi.render(scene, W, H)
+    for variant in (0, 1, 3, 26):
+        renderer.set_variant(variant)
+        renderer.upload_scene(scene)
+        renderer.set_scene_params(scene, W, H)
+        renderer.set_rows(0, 1, False)
+        renderer.set_output(None)
+        renderer.set_debug_rgb(True)
+        renderer.render()
+        px, rgb = renderer.read_framebuffer(), renderer.read_debug_rgb()
+        assert np.array_equal(np.isfinite(rgb), np.isfinite(orgb)), f"close seed {seed} variant {variant}\n{text}"
+        same = (rgb.view(np.uint32) == orgb.view(np.uint32)) | (np.isnan(rgb) & np.isnan(orgb))
+        assert same.all(), f"close seed {seed} variant {variant}: {int((~same).sum())} float RGB values not bit-identical\n{text}"
+        assert np.array_equal(px["rgba"], opx["rgba"]), f"close seed {seed} variant {variant}: packed bytes differ\n{text}"
+
+
 @pytest.mark.parametrize("round_", range(int(os.environ.get("RPT_FUZZ_ROUNDS", "8"))))
 def test_random_scenes_three_in_flight(round_):
     """Three contexts render three DIFFERENT random scenes at once (submitted back to back, nothing waited for in

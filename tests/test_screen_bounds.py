@@ -150,15 +150,39 @@ def test_rectangles_contain_every_hit_extreme_boosts(seed):
     check_scene(scene, 160, 90, f"extreme {seed}")
 
 
-@pytest.mark.parametrize("kind,seed", [("extreme", 28819), ("extreme", 7100), ("random", 1919)])
+def close_scene(seed):
+    """scene_fuzz.close_scene_text: large objects a few of their own sizes from the camera (tests/test_gpu_fuzz.py renders the same)."""
+    from scene_fuzz import close_scene_text
+    rng = np.random.default_rng(770000 + seed)
+    scene = Scene()
+    scene.inputScene(close_scene_text(rng))
+    v = rng.normal(size=3)
+    v = v / np.linalg.norm(v) * rng.choice([0.0, 0.3, 0.7, 0.9, 0.97])
+    scene.set_camera(tuple(float(c) for c in v), float(rng.uniform(-2, 6)))
+    scene.update_objects()
+    return scene
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_rectangles_contain_every_hit_large_close_objects(seed):
+    """Large boxes, slabs, rulers, spheres and meshes CLOSE to the camera at up to 0.99c: outlines that fill the screen, leave it and
+    pass near the camera.  90 000 more in a soak run; its three finds are kept below."""
+    W, H = [(160, 90), (128, 96), (200, 80)][seed % 3]
+    check_scene(close_scene(seed), W, H, f"close {seed}")
+
+
+@pytest.mark.parametrize("kind,seed", [("extreme", 28819), ("extreme", 7100), ("random", 1919), ("close", 755), ("close", 8660), ("close", 20897)])
 def test_rectangles_contain_every_hit_cases_the_soak_runs_found(kind, seed):
     """Three scenes that soak runs over 100 000 seeds found, each a different way of SAMPLING an outline too coarsely:
     extreme 28819 — a 10 x 2.5 x 12 cube at 0.9c next to a camera at 0.5c (relative gamma 3.5, nothing extreme about it): one of its
     edges passes so close that eight uniform segments put half the screen between two samples, and 296 pixels fell outside the
     diagonal bounds; extreme 7100 — a large box of which only a sliver at the bottom of the screen is visible: margins are
     relative to the on-screen extent, which was much smaller than the estimate the sampling tolerance came from; random 1919 —
-    an edge whose two corners and midpoint lie behind the camera while the stretch in between swings into view.  The outline is
-    now sampled adaptively in image space (Curve in rpt_screen_bounds.hpp)."""
+    an edge whose two corners and midpoint lie behind the camera while the stretch in between swings into view; close 755 — under a
+    relative gamma of 17 an edge whose corners and midpoint all map to u < -3 swings in to u = -0.23 between them (stretches far
+    off the screen had been skipped); close 8660 / 20897 — the visible end of an edge that leaves through the clip cone inside one
+    sixteenth of its length, seen by one sample or by none.  The outline is now sampled adaptively in image space (Curve in
+    rpt_screen_bounds.hpp), and what it cannot resolve gets the full plane."""
     if kind == "extreme":
         from scene_fuzz import extreme_scene_text
         rng = np.random.default_rng(550000 + seed)
@@ -170,6 +194,9 @@ def test_rectangles_contain_every_hit_cases_the_soak_runs_found(kind, seed):
         scene.update_objects()
         for W, H in ((160, 90), (320, 184)):
             check_scene(scene, W, H, f"extreme {seed} {W}x{H}")
+    elif kind == "close":
+        for W, H in ((160, 90), (200, 80), (320, 180)):
+            check_scene(close_scene(seed), W, H, f"close {seed} {W}x{H}")
     else:
         test_rectangles_contain_every_hit_random_scenes(seed)
 
