@@ -9,8 +9,9 @@
 // The object lies inside a bounding shape B in object space (the unit sphere, the cube [-1,1]^3, a mesh's root box), so a
 // ray can only hit it if F(nd) lies in K = { directions from oc that meet B }, a convex cone.  F is a homeomorphism of the
 // direction sphere (aberration = a Moebius map, then a linear map), so the region of camera directions to be kept is
-// bounded by G(boundary of K), G = F^-1:  the silhouette curve of B is sampled, every sample is mapped to a camera
-// direction and CHECKED by pushing it through F again with the very matrices the kernel uses, and the rectangle is the
+// bounded by G(boundary of K), G = F^-1:  the silhouette curve of B is sampled (adaptively, where the IMAGE of the curve
+// needs the samples: struct Curve below), every sample is mapped to a camera direction, a subset is CHECKED by pushing
+// it through F again with the very matrices the kernel uses, and the rectangle is the
 // bounding box of the samples' image-plane positions (plane z = 0.5: u = x/2z, v = y/2z), grown by a margin that covers
 // the curve between samples.  The region is cut off at the cone nd.z = EPS |nd| ("the horizon": a circle of radius ~25 on
 // the plane, far outside any screen): where the outline crosses it the crossing point is located, and the part of the
@@ -18,8 +19,11 @@
 // asking whether that object-space ray meets B — is added to the box, so a floor under the camera or an object half
 // behind it gets a rectangle that is open exactly on the sides where it runs off to infinity.  What is boxed is then the
 // complete boundary of a bounded planar region, so no inside/outside question is left open.  Every doubtful case — origin
-// inside or near B, non-finite numbers, a failed check — returns the full plane.  Arithmetic here may be approximate: it
-// only decides which exact tests are skipped, and a skipped test is one the reference would have failed for every pixel.
+// inside or near B, non-finite numbers, a failed check, an outline the sampling cannot resolve, an object so far away or so
+// strongly boosted that the kernel's own float arithmetic no longer follows the geometry — returns the full plane.
+// Arithmetic here may be approximate: it only decides which exact tests are skipped, and a skipped test is one the
+// reference would have failed for every pixel.  (What "would have failed" means is decided by the kernel's FLOAT results,
+// not by exact geometry: see sphere_rect.)
 #pragma once
 #include <algorithm>
 #include <cmath>
