@@ -69,3 +69,37 @@ def test_gpu_octree_repeats_the_build_when_a_list_outgrows_its_buffer(renderer, 
     cpu, gpu, _, _ = build_both(renderer, ["Models/bunny.obj"])
     a, b = cpu.buffers(), gpu.buffers()
     assert np.array_equal(a["octrees"], b["octrees"]) and np.array_equal(a["octreeTris"], b["octreeTris"])
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_gpu_octree_random_triangle_soups(renderer, tmp_path, seed):
+    """Random meshes the shipped ones do not resemble: triangle soups of 1 .. 3000 triangles — tiny, huge and sliver triangles,
+    zero-area ones, vertices shared by most of the mesh (the valence stop rule), all triangles in one corner of the box, flat
+    meshes (a root box of zero thickness) — built by the host builder and by the one-submission device builder: byte-identical."""
+    rng = np.random.default_rng(4242 + seed)
+    n_v = int(rng.choice([3, 8, 50, 400, 1500]))
+    n_t = int(rng.choice([1, 5, 60, 700, 3000]))
+    scale = rng.choice([1e-3, 1.0, 1.0, 50.0])
+    verts = rng.normal(size=(n_v, 3)) * scale
+    mode = seed % 4
+    if mode == 1:
+        verts[:, 2] = 0.25                                   # a flat mesh
+    if mode == 2:
+        verts[: n_v // 2] = verts[0] + rng.normal(size=(n_v // 2, 3)) * 1e-4 * scale      # half of the vertices in one spot
+    tris = rng.integers(0, n_v, size=(n_t, 3))
+    if mode == 3:
+        tris[:, 0] = 0                                        # one vertex in every triangle
+    degenerate = rng.random(n_t) < 0.05
+    tris[degenerate, 2] = tris[degenerate, 1]               # a few zero-area triangles
+    os.makedirs(tmp_path / "Models")
+    path = str(tmp_path / "Models" / f"soup{seed}.obj")
+    with open(path, "w") as f:
+        for v in verts:
+            f.write(f"v {v[0]:.6f} {v[1]:.6f} {v[2]:.6f}\n")
+        for t in tris:
+            f.write(f"f {t[0] + 1} {t[1] + 1} {t[2] + 1}\n")
+    cpu, gpu, _, _ = build_both(renderer, [path], asset_root="/")
+    a, b = cpu.buffers(), gpu.buffers()
+    for k in ("vertices", "normals", "triangles", "octreeTris", "octrees"):
+        assert a[k].shape == b[k].shape, (seed, k, a[k].shape, b[k].shape)
+        assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), f"soup {seed}: {k} differs"
