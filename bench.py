@@ -42,7 +42,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-DEFAULT_KERNEL = "rpt_render_kernel_ballot_w5 (rpt_render_async; the blocking rpt_render launches the same kernel with the mesh rows first)"   # what variant 0 launches (csrc/rpt_api.hip)
+# what variant 0 launches (csrc/rpt_api.hip): by whether the frame's Object[] holds a mesh
+DEFAULT_KERNEL = "rpt_render_kernel_ballot_w5 (rpt_render_async; the blocking rpt_render launches the same kernel with the mesh rows first)"
+DEFAULT_KERNEL_NO_MESH = "rpt_render_kernel_analytic_w8 (the default kernel without the octree walk compiled in: this workload's Object[] holds no mesh; 8 waves per SIMD)"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md): the contract roofline for this path
 
 WORKLOADS = {
@@ -383,7 +385,9 @@ def main():
         # the region = average number of launches running at once.  A launch's share of the device is then
         # duration / overlap, and achieved = bytes per launch / that (= bytes of all launches / wall time).
         overlap = max(1.0, kernel_sum_ms / (elapsed * 1e3)) if frame.depth > 1 else 1.0
-        kernel_name = (DEFAULT_KERNEL if args.variant == 0 else f"kernel variant {args.variant} (rpt_set_variant, include/rpt.h)")
+        has_mesh = bool((np.asarray(scene.objects()["type"]) == 2).any())
+        kernel_name = ((DEFAULT_KERNEL if has_mesh else DEFAULT_KERNEL_NO_MESH) if args.variant == 0
+                       else f"kernel variant {args.variant} (rpt_set_variant, include/rpt.h)")
         achieved = alg / (kernel_ms / overlap * 1e-3) / 1e9
         out = {
             "metric": "Mrays/s (primary rays) on Scenes/bunny.txt at 3840x2160" if (args.workload, W, H) == ("bunny", 3840, 2160)

@@ -108,13 +108,16 @@ int rpt_set_debug_rgb(rpt_ctx *ctx, void *device_ptr_or_null_or_1);
 
 /* Kernel variant: 0 = default (fastest validated); the others select alternative implementations of the same path for
  * A/B measurement.  All produce identical results.
- *   0   default: 41 for rpt_render_async, 43 for the blocking rpt_render; 1 when the octree's children are not stored consecutively
+ *   0   default: 44 when the current Object[] holds no mesh; else 41 for rpt_render_async, 43 for the blocking rpt_render;
+ *       1 when the octree's children are not stored consecutively
  *   1   reads the reference's Octree/triangle layouts only (any valid octree)
  *   3   derived layouts, every object tested for every pixel (no culling), 4 waves per SIMD
  *   26  per-tile object masks from a prepass kernel (round 1's default), 5 waves per SIMD
  *   40, 41, 42  no prepass: every wavefront builds its own object mask from per-object image-plane rectangles
  *               (computed on the host in rpt_set_objects) with one lane-parallel test + __ballot; 4 / 5 / 6 waves per SIMD
  *   43          41 with the band of tile rows that holds the meshes dispatched first (dispatch order only; whole-frame contexts)
+ *   44          41 without the octree walk compiled in (61 VGPRs, no scratch, 8 waves per SIMD): what frames without a mesh object
+ *               get; asked for explicitly while Object[] holds a mesh, 41 is launched instead
  *   50, 51      NOT bit-exact, opt-in only: 41 compiled with the arithmetic OpenCL C allows by default (fma contraction,
  *               2.5-ulp division, 3-ulp sqrt; csrc/rpt_relaxed.hip), 5 / 6 waves per SIMD.  Never chosen by variant 0.
  * The diagnostic kernels (7 loop counters, 8 primary rays only, 11 per-wave timeline) are not in the product library:
