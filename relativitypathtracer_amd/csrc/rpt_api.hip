@@ -45,6 +45,8 @@ struct Geometry {
     DeviceBuffer dnodes, dtris;               // derived layouts (rpt_kernels.hip.h)
     bool compact_ok = false;                  // derived octree layout usable (children consecutive)
     std::vector<float> host_node_bounds;      // min.xyz,max.xyz per octree node (culling spheres of mesh roots)
+    std::vector<uint8_t> node_holds_its_triangles;   // per node: every triangle of its list lies inside its box (true of a mesh's root
+                                                     // unless its list also holds an earlier mesh's triangles, Mesh.cpp:16-19)
     size_t vertex_count = 0, normal_count = 0, uv_count = 0, triangle_words = 0, octree_count = 0, octree_tri_count = 0;
     ~Geometry() {
         (void)hipSetDevice(device);
@@ -297,6 +299,8 @@ void build_dobjs(const rpt_ctx *ctx, const rpt_object *objs, int count, rptd::DO
         // a relative gamma beyond 20: the float evaluation of the boosted direction is too noisy for this approximate test
         finite = finite && std::isfinite(o.Lorentz[0].x) && std::fabs(o.Lorentz[0].x) <= 20.0f;
         d.rb = (finite && radius >= 0.0f && std::isfinite(radius)) ? radius * 1.02f + 1.0e-5f : -1.0f;
+        d.mesh_in_box = (o.type == RPT_MESH && o.meshIndex >= 0 && (size_t)o.meshIndex < ctx->geo->node_holds_its_triangles.size() &&
+                         ctx->geo->node_holds_its_triangles[(size_t)o.meshIndex] && ctx->geo->compact_ok) ? 1.0f : 0.0f;
         out[i] = d;
     }
 }
@@ -598,6 +602,21 @@ int rpt_upload_scene(rpt_ctx *ctx, const rpt_scene_desc *s) {
         float *b = &ctx->geo->host_node_bounds[6 * i];
         b[0] = s->octrees[i].min.x; b[1] = s->octrees[i].min.y; b[2] = s->octrees[i].min.z;
         b[3] = s->octrees[i].max.x; b[4] = s->octrees[i].max.y; b[5] = s->octrees[i].max.z;
+    }
+    // Which nodes hold all of their triangles inside their own box?  (Asked of mesh roots by the shadow-segment cull: a hit on a
+    // triangle is a point of that triangle.)  Indices were validated above.
+    ctx->geo->node_holds_its_triangles.assign(s->octree_count, 0);
+    for (size_t i = 0; i < s->octree_count; i++) {
+        const rpt_octree &o = s->octrees[i];
+        bool inside = o.trisCount >= 0;
+        for (int k = o.trisIndex; inside && k < o.trisIndex + o.trisCount; k++) {
+            const int t = s->octreeTris[k];
+            for (int c = 0; c < 3 && inside; c++) {
+                const rpt_float3 &v = s->vertices[s->triangles[9 * t + 3 * c]];
+                inside = v.x >= o.min.x && v.x <= o.max.x && v.y >= o.min.y && v.y <= o.max.y && v.z >= o.min.z && v.z <= o.max.z;
+            }
+        }
+        ctx->geo->node_holds_its_triangles[i] = inside ? 1 : 0;
     }
     ctx->scene_uploaded = true;
     const int rc = rpt_set_objects(ctx, s->objects, (int)s->object_count);

@@ -58,7 +58,8 @@ struct alignas(16) DObj {
     float rb;                                // bounding-sphere radius, inflated; < 0 = never cull this object
     float B[9];                              // object-space direction = B * nd + b for a camera direction nd
     float b[3];
-    float pad[3];
+    float mesh_in_box;                       // mesh objects: 1 = every triangle the octree can report lies inside the root's box
+    float pad[2];
 };
 static_assert(sizeof(DObj) == 96, "DObj");
 
@@ -547,6 +548,23 @@ RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, H
         const bool apart = ((origin.x > m) & (e.x > m)) | ((origin.x < -m) & (e.x < -m)) |
                            ((origin.y > m) & (e.y > m)) | ((origin.y < -m) & (e.y < -m)) |
                            ((origin.z > m) & (e.z > m)) | ((origin.z < -m) & (e.z < -m));
+        if (__ballot(!apart) == 0ull) return false;
+    }
+    // The same for a mesh whose root box holds all the triangles its octree lists (not so for a second mesh of a scene, whose
+    // lists also carry the first one's triangles, Mesh.cpp:16-19: the host says which): a hit below seg_max is a point of one of
+    // those triangles on the segment, so a segment that stays beyond one of the box's planes cannot produce one, and the
+    // normalisation, the slab test and the walk are skipped for the whole wave.  The margin covers the slab test's and the
+    // triangle test's float error (relative to the box and to the coordinates' size).
+    if (V >= 20 && seg_max > 0.0f && obj.type == RPT_MESH && a.dobjs[i].mesh_in_box != 0.0f) {
+        const DNode &root = a.dnodes[obj.meshIndex];
+        const float s = seg_max * 1.001f + 1.0e-4f;
+        const f3 e = origin + dir * s;
+        const float mx = 0.002f * (root.maxx - root.minx) + 2.0e-6f * (__builtin_fabsf(origin.x) + __builtin_fabsf(e.x)) + 1.0e-6f;
+        const float my = 0.002f * (root.maxy - root.miny) + 2.0e-6f * (__builtin_fabsf(origin.y) + __builtin_fabsf(e.y)) + 1.0e-6f;
+        const float mz = 0.002f * (root.maxz - root.minz) + 2.0e-6f * (__builtin_fabsf(origin.z) + __builtin_fabsf(e.z)) + 1.0e-6f;
+        const bool apart = ((origin.x > root.maxx + mx) & (e.x > root.maxx + mx)) | ((origin.x < root.minx - mx) & (e.x < root.minx - mx)) |
+                           ((origin.y > root.maxy + my) & (e.y > root.maxy + my)) | ((origin.y < root.miny - my) & (e.y < root.miny - my)) |
+                           ((origin.z > root.maxz + mz) & (e.z > root.maxz + mz)) | ((origin.z < root.minz - mz) & (e.z < root.minz - mz));
         if (__ballot(!apart) == 0ull) return false;
     }
     const float scale = length(dir);
