@@ -530,9 +530,10 @@ RPT_DEV bool sphere_core(const rpt_object &obj, f3 rayToSphere, float c, f3 dir,
 // active lane of the wave, the segment origin + dir * [0, seg_max] stays beyond one of that box's six planes (the segment's
 // bounding box against the unit box grown by a margin: three multiply-adds and twelve compares; a NaN compares false and
 // keeps the object), no lane can get an answer other than "not hit below seg_max", and the normalisation, its three IEEE
-// divisions and the intersector are skipped for the whole wave (__ballot).  Meshes are left alone: the reference's walk
-// accepts a triangle where the RAY meets its plane, which for another mesh's triangle in a leaf's list (Mesh.cpp:16-19)
-// can be outside the octree's box, and the ray-against-root-box question is the walk's own first test already.
+// divisions and the intersector are skipped for the whole wave (__ballot).  A mesh gets the same treatment against its root
+// box only where the host has found that every triangle its octree lists lies inside that box (DObj.mesh_in_box, below):
+// the reference's walk accepts a triangle where the RAY meets its plane, and a second mesh's lists also hold the first
+// mesh's triangles (Mesh.cpp:16-19), which can be anywhere — such a mesh is left alone.
 // (Measured also: the slab test with v_rcp_f32 as a second stage, and the same for mesh roots as a ray test: no
 // further gain on any scene — three quarter-rate reciprocals cost what they save)
 template <int V>
