@@ -17,6 +17,7 @@
 
 #include "../../include/rpt.h"
 #include "rpt_kernels.hip.h"
+#include "rpt_persistent.hip.h"
 #include "rpt_octree_build.hip.h"
 #include "rpt_screen_bounds.hpp"
 
@@ -42,15 +43,17 @@ void release(DeviceBuffer &b);
 struct Geometry {
     int device = 0;
     DeviceBuffer vertices, normals, uvs, triangles, octrees, octreeTris, textures;
-    DeviceBuffer dnodes, dtris;               // derived layouts (rpt_kernels.hip.h)
+    DeviceBuffer dnodes, dtris, dlinks;       // derived layouts (rpt_kernels.hip.h)
     bool compact_ok = false;                  // derived octree layout usable (children consecutive)
+    std::vector<int> node_new_index;          // reference node index -> index in the derived, breadth-first numbering
+    int top_count = 0;                        // derived nodes [0, top_count) are the forest's top levels (<= RPT_TOP_MAX)
     std::vector<float> host_node_bounds;      // min.xyz,max.xyz per octree node (culling spheres of mesh roots)
     std::vector<uint8_t> node_holds_its_triangles;   // per node: every triangle of its list lies inside its box (true of a mesh's root
                                                      // unless its list also holds an earlier mesh's triangles, Mesh.cpp:16-19)
     size_t vertex_count = 0, normal_count = 0, uv_count = 0, triangle_words = 0, octree_count = 0, octree_tri_count = 0;
     ~Geometry() {
         (void)hipSetDevice(device);
-        for (DeviceBuffer *b : {&vertices, &normals, &uvs, &triangles, &octrees, &octreeTris, &textures, &dnodes, &dtris}) release(*b);
+        for (DeviceBuffer *b : {&vertices, &normals, &uvs, &triangles, &octrees, &octreeTris, &textures, &dnodes, &dtris, &dlinks}) release(*b);
     }
 };
 
@@ -68,6 +71,9 @@ struct rpt_ctx {
     std::shared_ptr<Geometry> geo;                    // never null
     DeviceBuffer counters, wave_times;
     DeviceBuffer tile_masks;                          // per-tile object masks of the prepass
+    DeviceBuffer claim_counters;                      // persistent kernels: two sets of per-queue claim counters (rpt_persistent.hip.h)
+    int cu_count = 0;
+    unsigned int claim_epoch = 0;
     std::vector<uint8_t> host_objects;                // last Object[] (DObj depends on `interval`: rebuilt when it changes)
     DeviceBuffer dobjs;
     std::vector<rptb::Rect> rects;                    // last frame's per-object rectangles (reused for unchanged objects)
@@ -208,32 +214,75 @@ int validate_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
 // Derived octree layout: one 64-B DNode per node and one 48-B DTri per leaf triangle reference.
 // Only the numbers the reference stores (and B-A, C-A, which intersect_triangle would form from
 // them with the same IEEE subtraction) go in, so traversal results are unchanged.
+// Nodes are renumbered breadth first over the whole forest — every root, then every node of level 1, and so on — so that
+// (a) the eight children of a node stay consecutive (they are one block in the reference's numbering too, Octree.cpp:191-269)
+// and (b) the top levels of every octree are the first `top_count` records: the persistent kernels keep those nodes' links
+// in LDS.  Geometry::node_new_index maps the reference's node index (Object::meshIndex) to the derived one (DObj::root).
 int build_derived_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
-    ctx->geo->compact_ok = false;
+    Geometry &g = *ctx->geo;
+    g.compact_ok = false;
+    g.top_count = 0;
+    g.node_new_index.clear();
     if (s.octree_count == 0) {
-        ctx->geo->compact_ok = true;
-        if (int rc = reserve(ctx, ctx->geo->dnodes, 0)) return rc;
-        return reserve(ctx, ctx->geo->dtris, 0);
+        g.compact_ok = true;
+        if (int rc = reserve(ctx, g.dnodes, 0)) return rc;
+        if (int rc = reserve(ctx, g.dlinks, 0)) return rc;
+        return reserve(ctx, g.dtris, 0);
     }
-    std::vector<rptd::DNode> nodes(s.octree_count);
-    std::vector<rptd::DTri> tris;
-    for (size_t i = 0; i < s.octree_count; i++) {
+    const size_t n = s.octree_count;
+    if (n > (size_t)RPT_LINK_CHILD_MASK) return RPT_OK;                // a link holds 24 bits of child index
+    std::vector<uint8_t> is_child(n, 0);
+    for (size_t i = 0; i < n; i++) {
         const rpt_octree &o = s.octrees[i];
-        rptd::DNode &n = nodes[i];
-        std::memset(&n, 0, sizeof n);
-        n.minx = o.min.x; n.miny = o.min.y; n.minz = o.min.z;
-        n.maxx = o.max.x; n.maxy = o.max.y; n.maxz = o.max.z;
-        n.firstChild = o.children[0];
-        if (o.children[0] != -1)
-            for (int c = 1; c < 8; c++)
-                if (o.children[c] != o.children[0] + c) return RPT_OK;   // not consecutive: keep the general kernel
-        for (int c = 0; c < 6; c++) n.nb[c] = o.neighbors[c];
-        n.leafBegin = (int)tris.size();
-        n.leafCount = 0;
+        if (o.children[0] == -1) continue;
+        for (int c = 0; c < 8; c++) {
+            if (o.children[c] != o.children[0] + c) return RPT_OK;     // not consecutive: keep the general kernel
+            if (is_child[(size_t)o.children[c]]) return RPT_OK;        // a node with two parents: not a forest of trees
+            is_child[(size_t)o.children[c]] = 1;
+        }
+    }
+    std::vector<int> order;                                            // derived index -> reference index
+    order.reserve(n);
+    std::vector<int> &new_index = g.node_new_index;
+    new_index.assign(n, -1);
+    std::vector<int> level, next;
+    for (size_t i = 0; i < n; i++) if (!is_child[i]) level.push_back((int)i);
+    while (!level.empty()) {
+        next.clear();
+        for (int i : level) {
+            new_index[(size_t)i] = (int)order.size();
+            order.push_back(i);
+            if (s.octrees[i].children[0] != -1)
+                for (int c = 0; c < 8; c++) next.push_back(s.octrees[i].children[c]);
+        }
+        if (order.size() <= (size_t)RPT_TOP_MAX) g.top_count = (int)order.size();    // whole levels only
+        level.swap(next);
+    }
+    if (order.size() != n) return RPT_OK;                              // (cannot happen after validate_geometry: every node is a root or a child)
+    std::vector<rptd::DNode> nodes(n);
+    std::vector<int32_t> links(n);
+    std::vector<rptd::DTri> tris;
+    for (size_t k = 0; k < n; k++) {
+        const rpt_octree &o = s.octrees[order[k]];
+        rptd::DNode &d = nodes[k];
+        std::memset(&d, 0, sizeof d);
+        d.minx = o.min.x; d.miny = o.min.y; d.minz = o.min.z;
+        d.maxx = o.max.x; d.maxy = o.max.y; d.maxz = o.max.z;
+        d.link = -1;
+        if (o.children[0] != -1) {
+            unsigned int leaf_mask = 0;
+            for (int c = 0; c < 8; c++) leaf_mask |= (s.octrees[o.children[c]].children[0] == -1 ? 1u : 0u) << c;
+            d.link = (int)((unsigned int)new_index[(size_t)o.children[0]] | (leaf_mask << 24));
+            if (d.link == -1) return RPT_OK;                            // (first child 0xffffff with eight leaf children: reserved for "leaf")
+        }
+        links[k] = d.link;
+        for (int c = 0; c < 6; c++) d.nb[c] = o.neighbors[c] == -1 ? -1 : new_index[(size_t)o.neighbors[c]];
+        d.leafBegin = (int)tris.size();
+        d.leafCount = 0;
         if (o.children[0] == -1) {
-            n.leafCount = o.trisCount;
-            for (int k = o.trisIndex; k < o.trisIndex + o.trisCount; k++) {
-                const int t = s.octreeTris[k];
+            d.leafCount = o.trisCount;
+            for (int t0 = o.trisIndex; t0 < o.trisIndex + o.trisCount; t0++) {
+                const int t = s.octreeTris[t0];
                 const rpt_float3 &A = s.vertices[s.triangles[9 * t + 0]];
                 const rpt_float3 &B = s.vertices[s.triangles[9 * t + 3]];
                 const rpt_float3 &C = s.vertices[s.triangles[9 * t + 6]];
@@ -248,9 +297,12 @@ int build_derived_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
         }
     }
     if (tris.size() > (size_t)0x7fffffff) return RPT_OK;
-    if (int rc = upload(ctx, ctx->geo->dnodes, nodes.data(), nodes.size() * sizeof(rptd::DNode))) return rc;
-    if (int rc = upload(ctx, ctx->geo->dtris, tris.data(), tris.size() * sizeof(rptd::DTri))) return rc;
-    ctx->geo->compact_ok = true;
+    // (16 B of slack behind the triangle records: the cooperative 16-B staging loads of the persistent kernels never start past the
+    // last record, but keep the buffer's end away from them all the same)
+    if (int rc = upload(ctx, g.dnodes, nodes.data(), nodes.size() * sizeof(rptd::DNode))) return rc;
+    if (int rc = upload(ctx, g.dlinks, links.data(), links.size() * sizeof(int32_t))) return rc;
+    if (int rc = upload(ctx, g.dtris, tris.data(), tris.size() * sizeof(rptd::DTri))) return rc;
+    g.compact_ok = true;
     return RPT_OK;
 }
 
@@ -299,6 +351,8 @@ void build_dobjs(const rpt_ctx *ctx, const rpt_object *objs, int count, rptd::DO
         // a relative gamma beyond 20: the float evaluation of the boosted direction is too noisy for this approximate test
         finite = finite && std::isfinite(o.Lorentz[0].x) && std::fabs(o.Lorentz[0].x) <= 20.0f;
         d.rb = (finite && radius >= 0.0f && std::isfinite(radius)) ? radius * 1.02f + 1.0e-5f : -1.0f;
+        d.root = (o.type == RPT_MESH && ctx->geo->compact_ok && o.meshIndex >= 0 && (size_t)o.meshIndex < ctx->geo->node_new_index.size())
+                     ? ctx->geo->node_new_index[(size_t)o.meshIndex] : 0;
         d.mesh_in_box = (o.type == RPT_MESH && o.meshIndex >= 0 && (size_t)o.meshIndex < ctx->geo->node_holds_its_triangles.size() &&
                          ctx->geo->node_holds_its_triangles[(size_t)o.meshIndex] && ctx->geo->compact_ok) ? 1.0f : 0.0f;
         out[i] = d;
@@ -371,6 +425,62 @@ int local_tile_count(const rpt_ctx *ctx) {
     return full_periods * run + (rest < run ? rest : run);
 }
 
+// The band of tile rows that holds the meshes' screen rectangles (whole-frame contexts only), grown by one row each way:
+// where the frame's longest waves live.  false: no such band.
+bool mesh_band(const rpt_ctx *ctx, float aspect, int tile_rows, int &ty0, int &ty1) {
+    if (!(ctx->first_tile == 0 && ctx->tile_step == 1 && ctx->run_log2 == 0 && ctx->rects.size() == (size_t)ctx->object_count)) return false;
+    float v0 = 3e38f, v1 = -3e38f;
+    const rpt_object *objs = (const rpt_object *)ctx->host_objects.data();
+    for (int i = 0; i < ctx->object_count; i++)
+        if (objs[i].type == RPT_MESH && ctx->rects[i].u0 <= ctx->rects[i].u1) {
+            v0 = std::min(v0, ctx->rects[i].v0);
+            v1 = std::max(v1, ctx->rects[i].v1);
+        }
+    if (!(v0 <= v1)) return false;
+    const float H = (float)ctx->height;
+    auto clampi = [](float x, int lo, int hi) { return x < (float)lo ? lo : (x > (float)hi ? hi : (int)x); };
+    ty0 = clampi(std::floor((v0 + 0.5f) * H / 8.0f) - 1, 0, tile_rows - 1);
+    ty1 = clampi(std::floor((v1 + 0.5f) * H / 8.0f) + 1, 0, tile_rows - 1);
+    (void)aspect;
+    return ty1 >= ty0;
+}
+
+// Persistent kernels (rpt_persistent.hip.h): claim geometry, counters, grid = what the chip holds at once.
+int launch_persistent(rpt_ctx *ctx, rptd::KernelArgs &a, int tiles, int v) {
+    a.tiles_x = (ctx->width + 7) / 8;
+    a.runs_x = (a.tiles_x + RPT_SKY_RUN - 1) / RPT_SKY_RUN;
+    a.first_ty = 0;
+    a.first_h = 0;
+    int ty0 = 0, ty1 = -1;
+    static const bool no_band = std::getenv("RPT_NO_BAND") != nullptr;      // (experiment knob)
+    if (!no_band && mesh_band(ctx, a.aspect, tiles, ty0, ty1)) { a.first_ty = ty0; a.first_h = ty1 - ty0 + 1; }
+    const long long band = (long long)a.first_h * a.tiles_x, sky = (long long)(tiles - a.first_h) * a.runs_x;
+    // index / tiles_x by multiplication with ceil(2^32 / tiles_x): exact while index * tiles_x < 2^32
+    if (a.runs_x < 2 || (band + sky + 64) * a.tiles_x >= (1ll << 32)) return -1;     // (tiny or enormous frames: the caller takes the per-tile-launch kernel)
+    a.tiles_x_magic = (unsigned int)((1ull << 32) / (unsigned long long)a.tiles_x + 1ull);
+    a.runs_x_magic = (unsigned int)((1ull << 32) / (unsigned long long)a.runs_x + 1ull);
+    a.band_tiles = (int)band;
+    a.sky_runs = (int)sky;
+    const size_t counter_bytes = (size_t)2 * RPT_CLAIM_QUEUES * RPT_CLAIM_STRIDE * sizeof(unsigned int);
+    if (!ctx->claim_counters.ptr) {
+        if (int rc = reserve(ctx, ctx->claim_counters, counter_bytes)) return rc;
+        RPT_HIP(ctx, hipMemsetAsync(ctx->claim_counters.ptr, 0, counter_bytes, ctx->stream));
+        ctx->claim_epoch = 0;
+    }
+    a.claim_set = (int)(ctx->claim_epoch++ & 1u);
+    unsigned int *claims = (unsigned int *)ctx->claim_counters.ptr;
+    const long long want = (band + sky + 3) / 4;
+    static const int wgs_per_cu = std::getenv("RPT_WGS_PER_CU") ? std::atoi(std::getenv("RPT_WGS_PER_CU")) : 5;     // (experiment knob)
+    const unsigned int wgs = (unsigned int)std::max(1ll, std::min((long long)ctx->cu_count * wgs_per_cu, want));
+    switch (v) {
+    case 60: hipLaunchKernelGGL(rptd::rpt_render_kernel_persistent_w5, dim3(wgs), dim3(256), 0, ctx->stream, a, a.out16, a.plane, a.debug_rgb, claims); break;
+    case 62: hipLaunchKernelGGL(rptd::rpt_render_kernel_persistent_direct_w5, dim3(wgs), dim3(256), 0, ctx->stream, a, a.out16, a.plane, a.debug_rgb, claims); break;
+    case 63: hipLaunchKernelGGL(rptd::rpt_render_kernel_persistent_classic_w5, dim3(wgs), dim3(256), 0, ctx->stream, a, a.out16, a.plane, a.debug_rgb, claims); break;
+    default: return fail(ctx, RPT_ERR_ARG, "unknown persistent kernel variant");
+    }
+    return RPT_OK;
+}
+
 int launch(rpt_ctx *ctx) {
     if (!ctx->scene_uploaded) return fail(ctx, RPT_ERR_STATE, "rpt_render before rpt_upload_scene");
     if (!ctx->params_set) return fail(ctx, RPT_ERR_STATE, "rpt_render before rpt_set_params");
@@ -380,6 +490,8 @@ int launch(rpt_ctx *ctx) {
     std::memset(&a, 0, sizeof a);
     a.dnodes = (const rptd::DNode *)ctx->geo->dnodes.ptr;
     a.dtris = (const rptd::DTri *)ctx->geo->dtris.ptr;
+    a.links = (const int *)ctx->geo->dlinks.ptr;
+    a.top_count = ctx->geo->top_count;
     a.dobjs = (const rptd::DObj *)((const char *)ctx->objects.ptr + (size_t)ctx->object_count * sizeof(rpt_object));
     a.objects = (const rpt_object *)ctx->objects.ptr;
     a.rects = (const float4 *)((const char *)ctx->objects.ptr + (size_t)ctx->object_count * (sizeof(rpt_object) + sizeof(rptd::DObj)));
@@ -433,6 +545,12 @@ int launch(rpt_ctx *ctx) {
     int v = ctx->variant == 0 ? (!ctx->has_mesh ? 44 : (ctx->latency_call ? 43 : 41)) : ctx->variant;
     if (v == 44 && ctx->has_mesh) v = 41;          // (asked for explicitly on a scene with meshes: the full kernel)
     if (!ctx->geo->compact_ok && v != 44) v = 1;
+    if (v == 60 || v == 62 || v == 63) {
+        const int rc = launch_persistent(ctx, a, tiles, v);
+        if (rc > 0) return rc;
+        if (rc == 0) { RPT_HIP(ctx, hipGetLastError()); return RPT_OK; }
+        v = 41;
+    }
     switch (v) {
     case 1: hipLaunchKernelGGL(rptd::rpt_render_kernel_v0, grid, dim3(256), 0, ctx->stream, a); break;
     case 3: hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_w4, grid, dim3(256), 0, ctx->stream, a); break;
@@ -440,7 +558,7 @@ int launch(rpt_ctx *ctx) {
         const int tiles_x = ((ctx->width + 31) / 32) * 4;          // tiles per row as the 32-pixel-wide blocks see them
         const int n_tiles = tiles_x * tiles;
         if (int rc = reserve(ctx, ctx->tile_masks, (size_t)n_tiles * 8)) return rc;
-        a.tiles_x = tiles_x;
+        a.mask_tiles_x = tiles_x;
         a.n_tiles = n_tiles;
         a.tile_masks = (unsigned long long *)ctx->tile_masks.ptr;
         hipLaunchKernelGGL(rptd::rpt_tile_bin_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, ctx->stream, a);
@@ -451,7 +569,12 @@ int launch(rpt_ctx *ctx) {
     case 41: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w5, grid, dim3(256), 0, ctx->stream, a); break;
     case 42: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w6, grid, dim3(256), 0, ctx->stream, a); break;
     case 44: hipLaunchKernelGGL(rptd::rpt_render_kernel_analytic_w8, grid, dim3(256), 0, ctx->stream, a); break;
-    case 43: {   // 41 with the mesh region dispatched first (whole-frame contexts only)
+    case 256: hipLaunchKernelGGL(rptd::rpt_render_kernel_x256, grid, dim3(256), 0, ctx->stream, a); break;
+    case 257: hipLaunchKernelGGL(rptd::rpt_render_kernel_x257, grid, dim3(256), 0, ctx->stream, a); break;
+    case 259: hipLaunchKernelGGL(rptd::rpt_render_kernel_x259, grid, dim3(256), 0, ctx->stream, a); break;
+    case 261: hipLaunchKernelGGL(rptd::rpt_render_kernel_x261, grid, dim3(256), 0, ctx->stream, a); break;
+    case 263: hipLaunchKernelGGL(rptd::rpt_render_kernel_x263, grid, dim3(256), 0, ctx->stream, a); break;
+    case 43: case 265: case 269: {   // 41 with the mesh region dispatched first (whole-frame contexts only)
         a.first_w = 0; a.first_h = 0;
         if (ctx->first_tile == 0 && ctx->tile_step == 1 && ctx->run_log2 == 0 && ctx->rects.size() == (size_t)ctx->object_count) {
             // union of the mesh objects' screen rectangles, in strips (32 px) and tile rows (8 px), grown by one
@@ -476,7 +599,9 @@ int launch(rpt_ctx *ctx) {
                 }
             }
         }
-        hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_first_w5, grid, dim3(256), 0, ctx->stream, a);
+        if (v == 265) hipLaunchKernelGGL(rptd::rpt_render_kernel_x265, grid, dim3(256), 0, ctx->stream, a);
+        else if (v == 269) hipLaunchKernelGGL(rptd::rpt_render_kernel_x269, grid, dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_first_w5, grid, dim3(256), 0, ctx->stream, a);
         break;
     }
     case 50:
@@ -532,6 +657,7 @@ int rpt_create(rpt_ctx **out, int device_ordinal) {
         return RPT_ERR_DEVICE;
     }
     ctx->stream = ctx->own_stream;
+    if (hipDeviceGetAttribute(&ctx->cu_count, hipDeviceAttributeMultiprocessorCount, device_ordinal) != hipSuccess || ctx->cu_count <= 0) ctx->cu_count = 256;
     *out = ctx;
     return RPT_OK;
 }
@@ -556,7 +682,7 @@ void rpt_destroy(rpt_ctx *ctx) {
     // have destroyed: wait for the device rather than for a handle that may be dead, then free
     (void)hipDeviceSynchronize();
     ctx->geo.reset();
-    for (DeviceBuffer *b : {&ctx->objects, &ctx->dobjs, &ctx->counters, &ctx->wave_times, &ctx->tile_masks, &ctx->owned_out, &ctx->owned_plane, &ctx->owned_rgb})
+    for (DeviceBuffer *b : {&ctx->objects, &ctx->dobjs, &ctx->counters, &ctx->wave_times, &ctx->tile_masks, &ctx->claim_counters, &ctx->owned_out, &ctx->owned_plane, &ctx->owned_rgb})
         release(*b);
     if (ctx->pinned_objects) (void)hipHostFree(ctx->pinned_objects);
     for (hipEvent_t e : ctx->staging_done) if (e) (void)hipEventDestroy(e);
@@ -757,7 +883,7 @@ int rpt_object_screen_bounds(const void *object, int interval, const float *root
 int rpt_set_variant(rpt_ctx *ctx, int variant) {
     if (!ctx) return RPT_ERR_ARG;
     switch (variant) {
-    case 0: case 1: case 3: case 26: case 40: case 41: case 42: case 43: case 44: case 50: case 51: break;
+    case 0: case 1: case 3: case 26: case 40: case 41: case 42: case 43: case 44: case 50: case 51: case 60: case 62: case 63: case 256: case 257: case 259: case 261: case 263: case 265: case 269: break;
 #ifdef RPT_DIAGNOSTICS
     case 7: case 8: case 11: break;
 #endif

@@ -30,15 +30,19 @@ namespace rptd {
 
 #define RPT_EPSILON 0.0000001f       /* opencl_kernel.cl:6 */
 #define RPT_MAX_LEAF_STEPS 4096
+#define RPT_LINK_CHILD_MASK 0x00ffffff   /* DNode::link: low 24 bits = first child, high 8 = which children are leaves */
+#define RPT_TOP_MAX 3072                 /* node links of the octrees' top levels kept in LDS by the persistent kernels (12 KB) */
 #define RPT_PI_D 3.14159265358979323846264338327950288   /* OpenCL C M_PI (double) */
 
 // ---- derived, device-only layouts (built by the library at upload / per frame; values are the
 // reference's own numbers or IEEE results of the reference's own operations, so nothing rounds
 // differently) ----------------------------------------------------------------------------------
 // One octree node in one 64-B line.  Children of a node are consecutive in the reference's builder
-// (Octree.cpp:191-211 pushes the eight children back to back), so children[k] = firstChild + k.
+// (Octree.cpp:191-269 pushes the eight children back to back), so children[k] = firstChild + k.
+// The derived array is numbered breadth first over the whole forest (all roots, then all nodes of level 1, ...): the top levels
+// of every octree are the first KernelArgs::top_count records, which is what the persistent kernels keep in LDS.
 struct alignas(64) DNode {
-    float minx, miny, minz; int firstChild;      // -1 = leaf
+    float minx, miny, minz; int link;            // -1 = leaf; else firstChild | (leaf mask of the eight children) << 24
     float maxx, maxy, maxz; int leafBegin;       // first DTri of a leaf
     int leafCount; int nb[6]; int pad;           // neighbours -z,+z,-x,+x,-y,+y
 };
@@ -59,7 +63,8 @@ struct alignas(16) DObj {
     float B[9];                              // object-space direction = B * nd + b for a camera direction nd
     float b[3];
     float mesh_in_box;                       // mesh objects: 1 = every triangle the octree can report lies inside the root's box
-    float pad[2];
+    int root;                                // mesh objects: the root's index in the derived (breadth-first) node numbering
+    float pad;
 };
 static_assert(sizeof(DObj) == 96, "DObj");
 
@@ -89,12 +94,22 @@ struct KernelArgs {
     float ambient;
     float hable_wp[3];       // hable(white_point), host-computed
     // per-tile object masks: 8x8-pixel tiles of this context's rows, classified once per frame by rpt_tile_bin_kernel
-    int tiles_x, n_tiles;                    // tiles per row, tiles in this context's rows
+    int mask_tiles_x, n_tiles;               // tiles per row, tiles in this context's rows
     unsigned long long *tile_masks;          // [n_tiles] bit i = primary rays of the tile may hit object i (i < 64)
     // ---- the scene
     const DNode *dnodes;
     const DTri *dtris;
     const DObj *dobjs;
+    const int *links;               // DNode::link of every node again, 4 B apart: what a descent reads below the levels held in LDS
+    int top_count;                  // nodes [0, top_count) are the forest's top levels (whole levels, <= RPT_TOP_MAX)
+    // persistent kernels (rpt_persistent.hip.h): the band of tile rows that holds the meshes (first_ty, first_h above) is
+    // claimed tile by tile from per-queue counters, the other rows are dealt statically in runs of RPT_SKY_RUN tiles
+    int tiles_x;                    // 8x8 tiles per row of tiles
+    unsigned int tiles_x_magic;     // ceil(2^32 / tiles_x): t / tiles_x = mulhi(t, magic) for every t the host allows
+    int runs_x;                     // runs per row of tiles outside the band
+    unsigned int runs_x_magic;
+    int band_tiles, sky_runs;
+    int claim_set;                  // which of the two counter sets this launch counts in
     const rpt_object *objects;
     const rpt_float3 *vertices;
     const rpt_float3 *normals;
@@ -268,9 +283,9 @@ template <> struct NodeRef<1> {
     }
     RPT_DEV f3 bmin(const KernelArgs &) const { return mk3(lo.x, lo.y, lo.z); }
     RPT_DEV f3 bmax(const KernelArgs &) const { return mk3(hi.x, hi.y, hi.z); }
-    RPT_DEV int first_child() const { return __float_as_int(lo.w); }
-    RPT_DEV bool is_leaf(const KernelArgs &) const { return first_child() == -1; }
-    RPT_DEV int child(const KernelArgs &, int k) const { return first_child() + k; }
+    RPT_DEV int link() const { return __float_as_int(lo.w); }
+    RPT_DEV bool is_leaf(const KernelArgs &) const { return link() == -1; }
+    RPT_DEV int child(const KernelArgs &, int k) const { return (link() & RPT_LINK_CHILD_MASK) + k; }
     RPT_DEV int neighbor(const KernelArgs &, int side) const {   // select chain: no dynamic register indexing
         int r = q2.y;
         r = side == 1 ? q2.z : r;
@@ -308,7 +323,7 @@ RPT_DEV bool intersect_triangle_edges(f3 A, f3 v0v1, f3 v0v2, const Ray &ray, fl
     return true;
 }
 
-// opencl_kernel.cl:200-308 from the point where the ray is in object space.  newRay = object-space
+// opencl_kernel.cl:256-308 from the point where the ray is in object space.  newRay = object-space
 // ray (direction normalised); world_origin/world_dirlen are ray->origin.yzw and |ray->dir.yzw|.
 // Diagnostic cycle accounting (V == 4 only): per wave, shader-clock cycles and wave-level iteration counts of
 // the three loops of the walk, accumulated in LDS by the first active lane.
@@ -346,10 +361,10 @@ RPT_DEV bool exit_is_past_hit(f3 v, float hit_dist, bool didHit) {
 }
 
 template <int V>
-RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &newRay, f3 world_origin,
+RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin,
                          float world_dirlen, Hit &hit) {
-    NodeRef<(V == 0 ? 0 : 1)> node;   // V >= 1: derived layouts
-    int currOctreeIndex = obj.meshIndex;
+    NodeRef<(V == 0 ? 0 : 1)> node;   // V >= 1: derived layouts (root = the mesh's root in THEIR numbering, DObj::root)
+    int currOctreeIndex = root;
     node.load(a, currOctreeIndex);
     f2 d;
     int closeSide, farSide;
@@ -470,6 +485,142 @@ RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, const Ray &
     return true;
 }
 
+// ---- the same walk with its memory round trips re-ordered (V >= 256: flags in the low bits; results cannot differ: only WHEN
+// a record is asked for changes, never what is computed from it) -------------------------------------------------------------
+//   1: the exit face of a leaf does not depend on its triangles (getOppositeBoxSide works on the ray and the entry point alone),
+//      so it is found BEFORE the triangle loop and the neighbour's index is on its way while the triangles are tested
+//   2: ... and once that index is there (after the first triangle), so is the neighbour's record: the next leaf step starts with
+//      its node already in registers
+//   4: triangle records are asked for one iteration ahead
+struct NodeRec { v4f lo, hi; int count; };
+RPT_DEV NodeRec load_node_rec(const KernelArgs &a, int i) {
+    const v4f *p = reinterpret_cast<const v4f *>(a.dnodes + i);
+    NodeRec r;
+    r.lo = p[0];
+    r.hi = p[1];
+    r.count = a.dnodes[i].leafCount;
+    return r;
+}
+struct TriRec { v4f t0, t1; float e2z; int tri; };
+RPT_DEV TriRec load_tri_rec(const KernelArgs &a, int k) {
+    const v4f *p = reinterpret_cast<const v4f *>(a.dtris + k);
+    TriRec r;
+    r.t0 = p[0];
+    r.t1 = p[1];
+    const float2 t2 = *reinterpret_cast<const float2 *>(p + 2);
+    r.e2z = t2.x;
+    r.tri = __float_as_int(t2.y);
+    return r;
+}
+RPT_DEV void test_tri_rec(const TriRec &r, const Ray &ray, Hit &hit, int &hitTri, bool &didHit) {
+    float dist;
+    f2 triUV;
+    if (intersect_triangle_edges(mk3(r.t0.x, r.t0.y, r.t0.z), mk3(r.t0.w, r.t1.x, r.t1.y), mk3(r.t1.z, r.t1.w, r.e2z), ray, dist, triUV)) {
+        if (0 <= dist && dist < hit.dist) {
+            hitTri = r.tri;
+            hit.dist = dist;
+            hit.uv = triUV;
+            didHit = true;
+        }
+    }
+}
+
+template <int F>
+RPT_DEV bool octree_core_v2(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin,
+                            float world_dirlen, Hit &hit) {
+    int curr = root;
+    NodeRec rec = load_node_rec(a, curr);
+    f2 d;
+    int closeSide, farSide;
+    f3 nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z), nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
+    if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
+    f3 uv = newRay.origin + newRay.dir * d.x;
+    if (d.x < 0) {
+        uv = (newRay.origin - nmin) / (nmax - nmin);
+        if (__float_as_int(rec.lo.w) != -1) {
+            int link = __float_as_int(rec.lo.w);
+            while (link != -1) {
+                curr = (link & RPT_LINK_CHILD_MASK) + octree_child_step_fast(uv);
+                link = a.dnodes[curr].link;
+            }
+            rec = load_node_rec(a, curr);
+        }
+        nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
+        nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
+        if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
+        uv = newRay.origin + newRay.dir * d.x;
+    }
+    const ExitPlan plan = makeExitPlan(normalize(newRay.dir / (nmax - nmin)));
+    bool didHit = false;
+    int hitTri = 0;
+    for (int steps = 1; steps <= RPT_MAX_LEAF_STEPS; steps++) {
+        nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
+        nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
+        uv = (uv - nmin) / (nmax - nmin);
+        int link = __float_as_int(rec.lo.w);
+        if (link != -1) {
+            while (link != -1) {
+                curr = (link & RPT_LINK_CHILD_MASK) + octree_child_step_fast(uv);
+                link = a.dnodes[curr].link;
+            }
+            rec = load_node_rec(a, curr);
+            nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
+            nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
+        }
+        int i = __float_as_int(rec.hi.w);
+        const int trisEnd = i + rec.count;
+        // the way out, before the triangles
+        farSide = getOppositeBoxSide(plan, uv);
+        const int next = a.dnodes[curr].nb[farSide];
+        NodeRec nrec;
+        nrec.lo = nrec.hi = rec.lo;
+        nrec.count = 0;
+        if (F & 4) {
+            if (i < trisEnd) {
+                TriRec cur = load_tri_rec(a, i);
+                bool fetched = false;
+                for (; i < trisEnd; i++) {
+                    TriRec nxt = cur;
+                    if (i + 1 < trisEnd) nxt = load_tri_rec(a, i + 1);
+                    test_tri_rec(cur, newRay, hit, hitTri, didHit);
+                    if ((F & 2) && !fetched) { if (next != -1) nrec = load_node_rec(a, next); fetched = true; }
+                    cur = nxt;
+                }
+            } else if (F & 2) {
+                if (next != -1) nrec = load_node_rec(a, next);
+            }
+        } else {
+            if (i < trisEnd) {
+                test_tri_rec(load_tri_rec(a, i), newRay, hit, hitTri, didHit);
+                i++;
+            }
+            if (F & 2) { if (next != -1) nrec = load_node_rec(a, next); }
+            for (; i < trisEnd; i++) test_tri_rec(load_tri_rec(a, i), newRay, hit, hitTri, didHit);
+        }
+        uv = nmin + uv * (nmax - nmin);
+        const bool stop = exit_is_past_hit(uv - newRay.origin, hit.dist, didHit);
+        if (stop || next == -1) break;
+        curr = next;
+        rec = (F & 2) ? nrec : load_node_rec(a, curr);
+    }
+    if (!didHit) return false;
+    const float u = hit.uv.x, v = hit.uv.y;
+    const float w = 1.0f - u - v;
+    const f3 normA = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 0]]);
+    const f3 normB = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 1]]);
+    const f3 normC = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 2]]);
+    hit.normal = normalize(applyTranspose(obj.InvM, normA * w + normB * u + normC * v));
+    const rpt_float2 uvA = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 0]];
+    const rpt_float2 uvB = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 1]];
+    const rpt_float2 uvC = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 2]];
+    hit.uv.x = w * uvA.x + u * uvB.x + v * uvC.x;
+    hit.uv.y = w * uvA.y + u * uvB.y + v * uvC.y;
+    const f3 objPoint = newRay.origin + newRay.dir * hit.dist;
+    const f3 worldPoint = transformPoint(obj.M, objPoint);
+    hit.dist = length(worldPoint - world_origin) / world_dirlen;
+    return true;
+}
+
 RPT_DEV float max3(f3 v) { return cl_max(cl_max(v.x, v.y), v.z); }   // opencl_kernel.cl:310
 RPT_DEV float cube_winding(f3 origin) {
     return max3(mk3(__builtin_fabsf(origin.x), __builtin_fabsf(origin.y), __builtin_fabsf(origin.z))) < 1.0f ? -1.0f : 1.0f;
@@ -557,7 +708,7 @@ RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, H
     // normalisation, the slab test and the walk are skipped for the whole wave.  The margin covers the slab test's and the
     // triangle test's float error (relative to the box and to the coordinates' size).
     if (V >= 20 && seg_max > 0.0f && obj.type == RPT_MESH && a.dobjs[i].mesh_in_box != 0.0f) {
-        const DNode &root = a.dnodes[obj.meshIndex];
+        const DNode &root = a.dnodes[a.dobjs[i].root];
         const float s = seg_max * 1.001f + 1.0e-4f;
         const f3 e = origin + dir * s;
         const float mx = 0.002f * (root.maxx - root.minx) + 2.0e-6f * (__builtin_fabsf(origin.x) + __builtin_fabsf(e.x)) + 1.0e-6f;
@@ -582,7 +733,8 @@ RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, H
         Ray newRay;
         newRay.origin = origin;
         newRay.dir = dir;
-        return octree_core<V>(a, obj, newRay, yzw(origin4), length(yzw(dir4)), hit);
+        if (V >= 256) return octree_core_v2<(V & 7)>(a, obj, a.dobjs[i].root, newRay, yzw(origin4), length(yzw(dir4)), hit);
+        return octree_core<V>(a, obj, V == 0 ? obj.meshIndex : a.dobjs[i].root, newRay, yzw(origin4), length(yzw(dir4)), hit);
     }
     default:
         return false;
@@ -612,7 +764,8 @@ RPT_DEV bool intersect_object_primary(const KernelArgs &a, int i, f4 rayDir, Hit
         newRay.origin = origin;
         newRay.dir = dir;
         const f3 cam3 = mk3(obj.stationaryCam.y, obj.stationaryCam.z, obj.stationaryCam.w);
-        return octree_core<V>(a, obj, newRay, cam3, length(d3), hit);
+        if (V >= 256) return octree_core_v2<(V & 7)>(a, obj, pre.root, newRay, cam3, length(d3), hit);
+        return octree_core<V>(a, obj, pre.root, newRay, cam3, length(d3), hit);
     }
     default:
         return false;
@@ -832,7 +985,7 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
     }
     int tile_row = (int)blockIdx.y;              // 8-row tiles of this context, natural order
     int strip = (int)blockIdx.x;                 // 32-pixel-wide strip of that row
-    if (V == 23 && a.first_h > 0) {
+    if ((V == 23 || (V >= 256 && (V & 8))) && a.first_h > 0) {
         // Workgroups are handed out in the order of their linear index, i.e. row of strips by row of strips.  One frame at a
         // time, what ends the frame is the last of its long waves, so the band of tile rows that holds the meshes goes first
         // (whole rows, in their natural order: neighbours stay neighbours) and the other rows follow in order.
@@ -855,7 +1008,7 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
     bool traced = false;
     uint32_t packed = a.bg_packed;
     if (V == 10) {   // per-tile object mask of the prepass
-        const int tile = __builtin_amdgcn_readfirstlane(tile_row * a.tiles_x + (int)blockIdx.x * 4 + wave);
+        const int tile = __builtin_amdgcn_readfirstlane(tile_row * a.mask_tiles_x + (int)blockIdx.x * 4 + wave);
         object_mask = a.tile_masks[tile];
     }
     const bool masked = V == 10 || V >= 20;
@@ -911,6 +1064,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_analytic_w8(const KernelArgs a) { render_pixel_body<24>(a); }     // 44
 // V = 23: 20 + the strips that hold the meshes handed out first (dispatch order only)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_first_w5(const KernelArgs a) { render_pixel_body<23>(a); }   // 43
+// experiment arms of round 3 (walk with re-ordered round trips): 257, 259, 261, 263 (+8: mesh band first)
+#define RPT_X_KERNEL(N) __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_x##N(const KernelArgs a) { render_pixel_body<N>(a); }
+RPT_X_KERNEL(256) RPT_X_KERNEL(257) RPT_X_KERNEL(259) RPT_X_KERNEL(261) RPT_X_KERNEL(263) RPT_X_KERNEL(265) RPT_X_KERNEL(269)
 #ifdef RPT_DIAGNOSTICS   /* librpt_hip_diag.so only (make diag): loop counters, primary rays only, per-wave timeline */
 __global__ __launch_bounds__(256) void rpt_render_kernel_v1_diag(const KernelArgs a) { render_pixel_body<2>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_timeline(const KernelArgs a) { render_pixel_body<4>(a); }
@@ -938,7 +1094,7 @@ __global__ __launch_bounds__(256) void rpt_tile_bin_kernel(const KernelArgs a) {
     const bool valid = tile < a.n_tiles;
     unsigned long long mask = 0;
     if (valid) {
-        const int tx = tile % a.tiles_x, trow = tile / a.tiles_x;
+        const int tx = tile % a.mask_tiles_x, trow = tile / a.mask_tiles_x;
         const float x0 = (float)(tx * 8);
         const float y0 = (float)(((trow >> a.run_log2) * a.tile_step + a.first_tile + (trow & ((1 << a.run_log2) - 1))) * RPT_TILE_ROWS);
         const float xs[5] = {x0 + 3.5f, x0 - 0.5f, x0 + 7.5f, x0 - 0.5f, x0 + 7.5f};
