@@ -569,6 +569,13 @@ int launch(rpt_ctx *ctx) {
     case 41: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w5, grid, dim3(256), 0, ctx->stream, a); break;
     case 42: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w6, grid, dim3(256), 0, ctx->stream, a); break;
     case 44: hipLaunchKernelGGL(rptd::rpt_render_kernel_analytic_w8, grid, dim3(256), 0, ctx->stream, a); break;
+    case 61: hipLaunchKernelGGL(rptd::rpt_render_kernel_queue_w5, grid, dim3(256), 0, ctx->stream, a); break;
+    case 273: hipLaunchKernelGGL(rptd::rpt_render_kernel_x273, grid, dim3(256), 0, ctx->stream, a); break;
+    case 277: hipLaunchKernelGGL(rptd::rpt_render_kernel_x277, grid, dim3(256), 0, ctx->stream, a); break;
+    case 1257: hipLaunchKernelGGL(rptd::rpt_render_kernel_x257_w6, grid, dim3(256), 0, ctx->stream, a); break;
+    case 2257: hipLaunchKernelGGL(rptd::rpt_render_kernel_x257_w4, grid, dim3(256), 0, ctx->stream, a); break;
+    case 2259: hipLaunchKernelGGL(rptd::rpt_render_kernel_x259_w4, grid, dim3(256), 0, ctx->stream, a); break;
+    case 2263: hipLaunchKernelGGL(rptd::rpt_render_kernel_x263_w4, grid, dim3(256), 0, ctx->stream, a); break;
     case 256: hipLaunchKernelGGL(rptd::rpt_render_kernel_x256, grid, dim3(256), 0, ctx->stream, a); break;
     case 257: hipLaunchKernelGGL(rptd::rpt_render_kernel_x257, grid, dim3(256), 0, ctx->stream, a); break;
     case 259: hipLaunchKernelGGL(rptd::rpt_render_kernel_x259, grid, dim3(256), 0, ctx->stream, a); break;
@@ -883,7 +890,7 @@ int rpt_object_screen_bounds(const void *object, int interval, const float *root
 int rpt_set_variant(rpt_ctx *ctx, int variant) {
     if (!ctx) return RPT_ERR_ARG;
     switch (variant) {
-    case 0: case 1: case 3: case 26: case 40: case 41: case 42: case 43: case 44: case 50: case 51: case 60: case 62: case 63: case 256: case 257: case 259: case 261: case 263: case 265: case 269: break;
+    case 0: case 1: case 3: case 26: case 40: case 41: case 42: case 43: case 44: case 50: case 51: case 60: case 61: case 62: case 63: case 273: case 277: case 1257: case 2257: case 2259: case 2263: case 256: case 257: case 259: case 261: case 263: case 265: case 269: break;
 #ifdef RPT_DIAGNOSTICS
     case 7: case 8: case 11: break;
 #endif

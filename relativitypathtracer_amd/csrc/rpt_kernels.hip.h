@@ -560,8 +560,10 @@ RPT_DEV bool octree_core_v2(const KernelArgs &a, const rpt_object &obj, int root
         int link = __float_as_int(rec.lo.w);
         if (link != -1) {
             while (link != -1) {
-                curr = (link & RPT_LINK_CHILD_MASK) + octree_child_step_fast(uv);
-                link = a.dnodes[curr].link;
+                const int k = octree_child_step_fast(uv);
+                curr = (link & RPT_LINK_CHILD_MASK) + k;
+                if ((F & 16) && ((link >> (24 + k)) & 1)) break;          // the link says this child is a leaf: no lookup
+                link = (F & 16) ? a.links[curr] : a.dnodes[curr].link;
             }
             rec = load_node_rec(a, curr);
             nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
@@ -733,7 +735,7 @@ RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, H
         Ray newRay;
         newRay.origin = origin;
         newRay.dir = dir;
-        if (V >= 256) return octree_core_v2<(V & 7)>(a, obj, a.dobjs[i].root, newRay, yzw(origin4), length(yzw(dir4)), hit);
+        if (V >= 256) return octree_core_v2<(V & 23)>(a, obj, a.dobjs[i].root, newRay, yzw(origin4), length(yzw(dir4)), hit);
         return octree_core<V>(a, obj, V == 0 ? obj.meshIndex : a.dobjs[i].root, newRay, yzw(origin4), length(yzw(dir4)), hit);
     }
     default:
@@ -764,7 +766,7 @@ RPT_DEV bool intersect_object_primary(const KernelArgs &a, int i, f4 rayDir, Hit
         newRay.origin = origin;
         newRay.dir = dir;
         const f3 cam3 = mk3(obj.stationaryCam.y, obj.stationaryCam.z, obj.stationaryCam.w);
-        if (V >= 256) return octree_core_v2<(V & 7)>(a, obj, pre.root, newRay, cam3, length(d3), hit);
+        if (V >= 256) return octree_core_v2<(V & 23)>(a, obj, pre.root, newRay, cam3, length(d3), hit);
         return octree_core<V>(a, obj, pre.root, newRay, cam3, length(d3), hit);
     }
     default:
@@ -1066,6 +1068,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_first_w5(const KernelArgs a) { render_pixel_body<23>(a); }   // 43
 // experiment arms of round 3 (walk with re-ordered round trips): 257, 259, 261, 263 (+8: mesh band first)
 #define RPT_X_KERNEL(N) __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_x##N(const KernelArgs a) { render_pixel_body<N>(a); }
+#define RPT_XW_KERNEL(N, W) __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) void rpt_render_kernel_x##N##_w##W(const KernelArgs a) { render_pixel_body<N>(a); }
+RPT_XW_KERNEL(257, 6) RPT_XW_KERNEL(257, 4) RPT_XW_KERNEL(263, 4) RPT_XW_KERNEL(259, 4) RPT_X_KERNEL(273) RPT_X_KERNEL(277)
 RPT_X_KERNEL(256) RPT_X_KERNEL(257) RPT_X_KERNEL(259) RPT_X_KERNEL(261) RPT_X_KERNEL(263) RPT_X_KERNEL(265) RPT_X_KERNEL(269)
 #ifdef RPT_DIAGNOSTICS   /* librpt_hip_diag.so only (make diag): loop counters, primary rays only, per-wave timeline */
 __global__ __launch_bounds__(256) void rpt_render_kernel_v1_diag(const KernelArgs a) { render_pixel_body<2>(a); }

@@ -40,8 +40,8 @@ struct QueuedResult { float dist, u, v; int tri; };      // tri < 0: no hit
 struct PersistentLds {
     float4 rects[128];                                   // per object: rectangle, diagonal slabs (KernelArgs::rects)
     int top_links[RPT_TOP_MAX];                          // DNode::link of nodes [0, top_count)
-    v4f tri_arena[4][RPT_ARENA_TRIS * 3];                // per wave: staged triangle records
 };
+struct ArenaLds { v4f tri[4][RPT_ARENA_TRIS * 3]; };      // per wave: staged triangle records
 struct QueueLds {
     QueuedRay rays[RPT_QUEUE_MAX];
     QueuedResult results[RPT_QUEUE_MAX];
@@ -50,11 +50,14 @@ struct QueueLds {
 };
 
 __shared__ PersistentLds rpt_plds;
+__shared__ ArenaLds rpt_alds;
 __shared__ QueueLds rpt_qlds;
 
 // (Written so that the LDS read and the global load stay two instructions: a select between the two ADDRESSES would make the
 // compiler issue one flat_load, which waits on both memory counters and takes the slow path through the aperture check.)
+template <bool TOPLDS>
 RPT_DEV int node_link(const KernelArgs &a, int idx) {
+    if (!TOPLDS) return a.links[idx];
     int w = *reinterpret_cast<const volatile int *>(&rpt_plds.top_links[idx < RPT_TOP_MAX ? idx : 0]);   // (volatile: keeps it a ds_read of its own)
     if (idx >= a.top_count) w = a.links[idx];
     return w;
@@ -62,13 +65,14 @@ RPT_DEV int node_link(const KernelArgs &a, int idx) {
 
 // From an inner node with link word w down to the leaf that holds uv (opencl_kernel.cl:256-261: the same child steps; only
 // what is READ per level differs — one link word instead of a node record).
+template <bool TOPLDS>
 RPT_DEV int descend_links(const KernelArgs &a, int w, f3 &uv) {
     int idx;
     for (;;) {
         const int k = octree_child_step_fast(uv);
         idx = (w & RPT_LINK_CHILD_MASK) + k;
         if ((w >> (24 + k)) & 1) break;          // that child is a leaf
-        w = node_link(a, idx);
+        w = node_link<TOPLDS>(a, idx);
     }
     return idx;
 }
@@ -85,7 +89,7 @@ RPT_DEV void load_box(const KernelArgs &a, int idx, f3 &nmin, f3 &nmax, int &lin
 // opencl_kernel.cl:200-286 for the lanes whose `alive` is set, called by ALL lanes of the wave in uniform control flow.
 // In: object-space ray (direction normalised), hit_dist = the caller's 1e20f.  Out: didHit, and for a hit the parametric
 // distance, the barycentric (u,v) and the triangle id (what opencl_kernel.cl:287-306 then works from: mesh_hit_finish).
-template <bool STAGE>
+template <bool STAGE, bool TOPLDS = true>
 RPT_DEV void walk_uniform(const KernelArgs &a, int wave, int root, f3 origin, f3 dir, bool alive, float &hit_dist, f2 &hit_uv,
                           int &hitTri, bool &didHit) {
     const int lane = threadIdx.x & 63;
@@ -103,7 +107,7 @@ RPT_DEV void walk_uniform(const KernelArgs &a, int wave, int root, f3 origin, f3
     if (alive && d.x < 0) {     // the ray starts inside the root: go to the leaf that holds the origin
         uv = (origin - nmin) / (nmax - nmin);
         if (link != -1) {
-            curr = descend_links(a, link, uv);
+            curr = descend_links<TOPLDS>(a, link, uv);
             load_box(a, curr, nmin, nmax, link, leafBegin);
         }
         alive = intersect_AABB(nmin, nmax, ray, d, closeSide, farSide);
@@ -112,7 +116,7 @@ RPT_DEV void walk_uniform(const KernelArgs &a, int wave, int root, f3 origin, f3
     const ExitPlan plan = makeExitPlan(normalize(dir / (nmax - nmin)));
     didHit = false;
     hitTri = 0;
-    v4f *arena = rpt_plds.tri_arena[wave];
+    v4f *arena = rpt_alds.tri[wave];
     for (int steps = 1; steps <= RPT_MAX_LEAF_STEPS; steps++) {
         alive = alive && curr != -1;
         if (__ballot(alive) == 0ull) break;
@@ -122,7 +126,7 @@ RPT_DEV void walk_uniform(const KernelArgs &a, int wave, int root, f3 origin, f3
             load_box(a, curr, nmin, nmax, link, leafBegin);
             uv = (uv - nmin) / (nmax - nmin);
             if (link != -1) {
-                curr = descend_links(a, link, uv);
+                curr = descend_links<TOPLDS>(a, link, uv);
                 load_box(a, curr, nmin, nmax, link, leafBegin);
             }
             leafCount = a.dnodes[curr].leafCount;
@@ -552,6 +556,282 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_persistent_direct_w5(RPT_PERSISTENT_PARAMS) { RPT_PERSISTENT_OUTPUTS; persistent_body<1>(a, o); }  // 62: A/B arm, triangle records straight from global memory
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_persistent_classic_w5(RPT_PERSISTENT_PARAMS) { RPT_PERSISTENT_OUTPUTS; persistent_body<2>(a, o); }  // 63: A/B arm
+
+// ================================================================================================================
+// The per-workgroup ray queue (variant 61).  A workgroup owns a 32x8-pixel strip, one 8x8 tile per wave, launched
+// like the default kernel.  Whatever needs an octree walk — a primary ray that enters a mesh's root box, a shadow ray that has to
+// be tested against a mesh — is not walked by the pixel's own lane: the lane pushes {object-space ray, pixel slot} into the
+// workgroup's LDS queue (__ballot + popcount prefix inside the wave, one ds_add per wave for the base), and after a barrier the
+// workgroup's waves pull 64 entries at a time and walk them with full lanes (walk_uniform), write {distance, barycentrics,
+// triangle} to the pixel's result slot, and after a second barrier every pixel continues with its own result.  Per-ray
+// arithmetic is the same functions with the same operands: bit-identical by construction.  Barriers sit only in control flow
+// that is uniform over the WORKGROUP (loops over objects and lights, the queue's count), never behind a per-wave condition.
+RPT_DEV int queue_push_slot(bool push) {         // the entry index for this lane's ray, -1 if it does not push
+    const unsigned long long m = __ballot(push);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (m != 0ull) {
+        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&rpt_qlds.count, __popcll(m));
+        base = __builtin_amdgcn_readlane(base, __ffsll((long long)m) - 1);
+    }
+    return push ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
+// walk every queued ray of object `root` (all waves; between two barriers)
+RPT_DEV void queue_drain(const KernelArgs &a, int wave, int root) {
+    const int lane = threadIdx.x & 63;
+    const int n = rpt_qlds.count;
+    for (int first = wave * 64; first < n; first += 256) {
+        const int e = first + lane;
+        const bool alive = e < n;
+        const QueuedRay r = rpt_qlds.rays[alive ? e : first];
+        float dist = 1e20f;
+        f2 uv;
+        uv.x = uv.y = 0.0f;
+        int tri;
+        bool got;
+        walk_uniform<false, false>(a, wave, root, mk3(r.ox, r.oy, r.oz), mk3(r.dx, r.dy, r.dz), alive, dist, uv, tri, got);
+        if (alive) {
+            QueuedResult q;
+            q.dist = dist; q.u = uv.x; q.v = uv.y; q.tri = got ? tri : -1;
+            rpt_qlds.results[r.pixel] = q;
+        }
+    }
+}
+
+// one mesh object for the whole strip: push, drain, read back.  `want`: this lane has a ray for the object.
+RPT_DEV bool queue_round(const KernelArgs &a, int wave, int root, bool want, f3 origin, f3 dir, float &dist, f2 &uv, int &tri) {
+    const int slot = threadIdx.x;
+    if (threadIdx.x == 0) rpt_qlds.count = 0;
+    rpt_qlds.results[slot].tri = -1;
+    __syncthreads();
+    // only rays that enter the root box are queued (the walk's own first test, opencl_kernel.cl:219: repeated by the walker)
+    if (want) {
+        const DNode &rn = a.dnodes[root];
+        Ray ray;
+        ray.origin = origin;
+        ray.dir = dir;
+        f2 d;
+        int cs, fs;
+        want = intersect_AABB(mk3(rn.minx, rn.miny, rn.minz), mk3(rn.maxx, rn.maxy, rn.maxz), ray, d, cs, fs);
+    }
+    const int e = queue_push_slot(want);
+    if (e >= 0) {
+        QueuedRay r;
+        r.dx = dir.x; r.dy = dir.y; r.dz = dir.z;
+        r.ox = origin.x; r.oy = origin.y; r.oz = origin.z;
+        r.pixel = slot;
+        r.pad = 0;
+        rpt_qlds.rays[e] = r;
+    }
+    __syncthreads();
+    if (rpt_qlds.count == 0) return false;                      // (workgroup-uniform: nobody asked; one barrier less)
+    queue_drain(a, wave, root);
+    __syncthreads();
+    const QueuedResult q = rpt_qlds.results[slot];
+    dist = q.dist;
+    uv.x = q.u;
+    uv.y = q.v;
+    tri = q.tri;
+    return q.tri >= 0;
+}
+
+RPT_DEV void render_strip_queued(const KernelArgs &a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile_row = (int)blockIdx.y, strip = (int)blockIdx.x;
+    const int global_tile = (tile_row >> a.run_log2) * a.tile_step + a.first_tile + (tile_row & ((1 << a.run_log2) - 1));
+    const int x_coord = strip * 32 + wave * 8 + (lane & 7);
+    const int y_coord = global_tile * RPT_TILE_ROWS + (lane >> 3);
+    const int local_row = tile_row * RPT_TILE_ROWS + (lane >> 3);
+    const bool valid = x_coord < a.width && y_coord < a.height;
+    const unsigned long long object_mask = wave_object_mask(a, strip * 32 + wave * 8, global_tile * RPT_TILE_ROWS);
+    // the strip's mask, formed the same way by every wave of the workgroup from the strip's own bounds (a rectangle that misses the
+    // 32x8 strip grown by 1.5 pixels misses each of its tiles grown by 1.5 pixels): what decides whether a barrier round happens
+    unsigned long long strip_mask;
+    {
+        const int n = a.object_count;
+        const int slot = (lane < n) ? lane : 0;
+        const float4 r = a.rects[2 * slot];
+        const float tu0 = (((float)(strip * 32) - 1.5f) * a.inv_width - 0.5f) * a.aspect, tu1 = (((float)(strip * 32) + 32.5f) * a.inv_width - 0.5f) * a.aspect;
+        const float tv0 = ((float)(global_tile * RPT_TILE_ROWS) - 1.5f) * a.inv_height - 0.5f, tv1 = ((float)(global_tile * RPT_TILE_ROWS) + 8.5f) * a.inv_height - 0.5f;
+        const bool outside = (r.z < tu0) | (r.x > tu1) | (r.w < tv0) | (r.y > tv1);
+        strip_mask = __ballot((lane < n) & !outside);
+    }
+    uint32_t packed = a.bg_packed;
+    f3 mapped = mk3(0.0f, 0.0f, 0.0f);
+    bool traced = false;
+    if (strip_mask == 0ull && a.object_count <= 64) {           // workgroup-uniform: nothing can be hit anywhere in the strip
+        if (valid) {
+            Outputs o;
+            o.out16 = a.out16; o.plane = a.plane; o.debug_rgb = a.debug_rgb; o.claims = nullptr;
+            store_tile_pixel(a, o, x_coord, y_coord, local_row, packed, traced, mapped);
+        }
+        return;
+    }
+    const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);
+    const f3 nd = normalize(camdir);
+    const f4 rayDir = mk4((float)a.interval, nd.x, nd.y, nd.z);
+    const float inf = 1e20f;
+    Hit hit;
+    hit.dist = inf;
+    hit.object = -1;
+    hit.normal = mk3(0, 0, 0);
+    hit.uv.x = hit.uv.y = 0.0f;
+    // ---- closest hit (opencl_kernel.cl:361-425), objects in their order
+    for (int i = 0; i < a.object_count; i++) {
+        const rpt_object &obj = a.objects[i];
+        const bool in_strip = i >= 64 || ((strip_mask >> i) & 1ull);
+        const bool in_tile = i >= 64 || ((object_mask >> i) & 1ull);
+        if (obj.type != RPT_MESH ? !in_tile : !in_strip) continue;          // wave-uniform for analytic objects, workgroup-uniform for meshes
+        const DObj &pre = a.dobjs[i];
+        const f3 d3 = mk3(dot(ld4(obj.Lorentz[1]), rayDir), dot(ld4(obj.Lorentz[2]), rayDir), dot(ld4(obj.Lorentz[3]), rayDir));
+        f3 dir = transformDirection(obj.InvM, d3);
+        const float scale = length(dir);
+        dir = dir / scale;
+        const f3 origin = mk3(pre.ox, pre.oy, pre.oz);
+        Hit newHit;
+        newHit.dist = inf;
+        bool got = false;
+        switch (obj.type) {
+        case RPT_SPHERE: got = sphere_core(obj, -origin, pre.sphere_c, dir, scale, newHit, obj.textureIndex != -1); break;
+        case RPT_CUBE: got = cube_core(obj, origin, pre.winding, dir, scale, newHit); break;
+        case RPT_MESH: {
+            int tri;
+            got = queue_round(a, wave, pre.root, valid && in_tile, origin, dir, newHit.dist, newHit.uv, tri);
+            if (got) mesh_hit_finish(a, obj, origin, dir, tri, mk3(obj.stationaryCam.y, obj.stationaryCam.z, obj.stationaryCam.w), length(d3), newHit);
+            break;
+        }
+        default: break;
+        }
+        if (valid && got && newHit.dist < hit.dist) {
+            hit = newHit;
+            hit.object = i;
+        }
+    }
+    // ---- shading (opencl_kernel.cl:548-604)
+    const bool h = hit.object >= 0;
+    const int ho_i = h ? hit.object : 0;
+    const rpt_object &ho = a.objects[ho_i];
+    f3 hcolor = mk3(0.0f, 0.0f, 0.0f), color = mk3(0.0f, 0.0f, 0.0f);
+    if (h) {
+        hcolor = ho.textureIndex != -1 ? sample_texture(a, ho, hit.uv) : ld3(ho.color);
+        if (ho.flashPeriod > 0) {
+            const float event_x = ho.stationaryCam.x + dot(ld4(ho.Lorentz[0]), rayDir) * hit.dist;
+            const float period = ho.flashPeriod;
+            const float duration = ho.flashDuration;
+            if (event_x - period * __builtin_floorf(event_x / period) < duration) hcolor = hcolor * 2;
+        }
+        color = hcolor * (a.interval != 0 ? a.ambient : 1.0f);
+        if (ho.light) color = color + hcolor;
+    }
+    if (a.interval != 0) {
+        for (int i = 0; i < a.object_count; i++) {
+            const rpt_object &lo = a.objects[i];
+            if (!lo.light) continue;                       // uniform
+            bool need = h && i != hit.object;
+            f4 hitPos = mk4(0, 0, 0, 0), lightDir = mk4(0, 0, 0, 1);
+            f3 lightDir3_ObjFrame = mk3(0, 0, 0);
+            float ndotl = 0.0f;
+            if (need) {
+                const f4 cameraPos_ObjFrame = ld4(ho.stationaryCam);
+                const f4 rayDir_ObjFrame = transformPoint4D(ho.Lorentz, rayDir);
+                f4 hitPos_ObjFrame = cameraPos_ObjFrame + rayDir_ObjFrame * hit.dist;
+                hitPos_ObjFrame = hitPos_ObjFrame + mk4(0, hit.normal.x * 0.001f, hit.normal.y * 0.001f, hit.normal.z * 0.001f);
+                hitPos = transformPoint4D(ho.InvLorentz, hitPos_ObjFrame);
+                const f4 hitPos_LightFrame = transformPoint4D(lo.Lorentz, hitPos);
+                const f3 lightPos3_LightFrame = mk3(lo.M[0].w, lo.M[1].w, lo.M[2].w);
+                const f3 lightDir3_LightFrame = lightPos3_LightFrame - yzw(hitPos_LightFrame);
+                const f4 lightDir_LightFrame = mk4(a.interval * length(lightDir3_LightFrame), lightDir3_LightFrame.x,
+                                                   lightDir3_LightFrame.y, lightDir3_LightFrame.z);
+                lightDir = transformPoint4D(lo.InvLorentz, lightDir_LightFrame);
+                const f4 lightDir_ObjFrame = transformPoint4D(ho.Lorentz, lightDir);
+                lightDir3_ObjFrame = yzw(lightDir_ObjFrame);
+                const f3 unitLightDir3 = normalize(lightDir3_ObjFrame);
+                ndotl = dot(hit.normal, unitLightDir3);
+                need = ndotl > 0;
+            }
+            // sample_light (opencl_kernel.cl:488-545): occluders in their order; a mesh occluder is one barrier round
+            const f3 ldn = normalize(yzw(lightDir));
+            const f4 lightDir0 = mk4((float)a.interval, ldn.x, ldn.y, ldn.z);
+            const float lightDist = length(yzw(lightDir));
+            bool occluded = false;
+            for (int j = 0; j < a.object_count; j++) {
+                if (j == i) continue;
+                const rpt_object &obj = a.objects[j];
+                const bool act = need && !occluded;
+                if (obj.type != RPT_MESH && __ballot(act) == 0ull) continue;       // (a mesh round has barriers: every wave goes through it)
+                const f4 ev = transformPoint4D(obj.Lorentz, hitPos);
+                const f4 ld = transformPoint4D(obj.Lorentz, lightDir0);
+                const f3 origin = transformPoint(obj.InvM, yzw(ev));
+                f3 dir = transformDirection(obj.InvM, yzw(ld));
+                bool want = act;
+                if (obj.type != RPT_MESH) {
+                    const float s = lightDist * 1.001f + 1.0e-4f, m = 1.002f + 0.75e-6f * dot(origin, origin);
+                    const f3 e = origin + dir * s;
+                    const bool apart = ((origin.x > m) & (e.x > m)) | ((origin.x < -m) & (e.x < -m)) |
+                                       ((origin.y > m) & (e.y > m)) | ((origin.y < -m) & (e.y < -m)) |
+                                       ((origin.z > m) & (e.z > m)) | ((origin.z < -m) & (e.z < -m));
+                    if (__ballot(act && !(apart && lightDist > 0.0f)) == 0ull) continue;
+                } else if (a.dobjs[j].mesh_in_box != 0.0f) {
+                    // per LANE here: a lane whose segment cannot reach the box does not queue a ray (the wave-wide form of this cull
+                    // in intersect_object skips only when no lane can)
+                    const DNode &root = a.dnodes[a.dobjs[j].root];
+                    const float s = lightDist * 1.001f + 1.0e-4f;
+                    const f3 e = origin + dir * s;
+                    const float mx = 0.002f * (root.maxx - root.minx) + 2.0e-6f * (__builtin_fabsf(origin.x) + __builtin_fabsf(e.x)) + 1.0e-6f;
+                    const float my = 0.002f * (root.maxy - root.miny) + 2.0e-6f * (__builtin_fabsf(origin.y) + __builtin_fabsf(e.y)) + 1.0e-6f;
+                    const float mz = 0.002f * (root.maxz - root.minz) + 2.0e-6f * (__builtin_fabsf(origin.z) + __builtin_fabsf(e.z)) + 1.0e-6f;
+                    const bool apart = ((origin.x > root.maxx + mx) & (e.x > root.maxx + mx)) | ((origin.x < root.minx - mx) & (e.x < root.minx - mx)) |
+                                       ((origin.y > root.maxy + my) & (e.y > root.maxy + my)) | ((origin.y < root.miny - my) & (e.y < root.miny - my)) |
+                                       ((origin.z > root.maxz + mz) & (e.z > root.maxz + mz)) | ((origin.z < root.minz - mz) & (e.z < root.minz - mz));
+                    want = act && !(apart && lightDist > 0.0f);
+                }
+                const float scale = length(dir);
+                dir = dir / scale;
+                Hit nh;
+                nh.dist = 1e20f;
+                bool got = false;
+                switch (obj.type) {
+                case RPT_SPHERE: {
+                    const f3 rayToSphere = -origin;
+                    if (act) got = sphere_core(obj, rayToSphere, dot(rayToSphere, rayToSphere) - 1.0f, dir, scale, nh, obj.textureIndex != -1);
+                    break;
+                }
+                case RPT_CUBE:
+                    if (act) got = cube_core(obj, origin, cube_winding(origin), dir, scale, nh);
+                    break;
+                case RPT_MESH: {
+                    int tri;
+                    got = queue_round(a, wave, a.dobjs[j].root, want, origin, dir, nh.dist, nh.uv, tri);
+                    if (got) mesh_hit_finish(a, obj, origin, dir, tri, yzw(ev), length(yzw(ld)), nh);
+                    break;
+                }
+                default: break;
+                }
+                if (act && got && nh.dist < lightDist) occluded = true;
+            }
+            if (need && !occluded) {
+                const float k = ndotl / (1.0f + 0.1f * length(lightDir3_ObjFrame) + 0.01f * dot(lightDir3_ObjFrame, lightDir3_ObjFrame));
+                color = color + hcolor * k * ld3(lo.color);
+            }
+        }
+    }
+    if (h) {
+        packed = tonemap_pack(a, color, mapped);
+        traced = true;
+    }
+    if (valid) {
+        Outputs o;
+        o.out16 = a.out16;
+        o.plane = a.plane;
+        o.debug_rgb = a.debug_rgb;
+        o.claims = nullptr;
+        store_tile_pixel(a, o, x_coord, y_coord, local_row, packed, traced, mapped);
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_queue_w5(const KernelArgs a) { render_strip_queued(a); }   // 61
 
 }  // namespace rptd
 #endif  /* !RPT_RELAXED_FP */

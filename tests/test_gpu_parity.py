@@ -41,7 +41,7 @@ SIZES = {"cube": (640, 480), "arch": (480, 270), "arch_t0": (480, 270), "bunny":
 EXACT = {"cube", "arch", "arch_t0", "bunny", "shadows", "cubes", "rulers", "ladder", "soccer"}   # every scene: textured spheres too (same explicit asin/atan2 on both sides)
 
 
-VARIANTS = [0, 1, 3, 26, 40, 41, 42, 43, 44, 60, 62, 63, 256, 257, 259, 261, 263, 265, 269]   # include/rpt.h: 0 = default (41 / 43 / 44); 1 = reference-layout kernel; 3 derived layouts, no culling; 26 prepass masks; 40-42 in-wave ballot cull; 44 = no octree walk compiled in (mesh-free frames)
+VARIANTS = [0, 1, 3, 26, 40, 41, 42, 43, 44, 60, 62, 63, 256, 257, 259, 261, 263, 265, 269, 273, 277, 1257, 2257, 2259, 2263, 61]   # include/rpt.h: 0 = default (41 / 43 / 44); 1 = reference-layout kernel; 3 derived layouts, no culling; 26 prepass masks; 40-42 in-wave ballot cull; 44 = no octree walk compiled in (mesh-free frames)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
