@@ -110,19 +110,31 @@ int rpt_set_debug_rgb(rpt_ctx *ctx, void *device_ptr_or_null_or_1);
  * A/B measurement.  All produce identical results.
  *   0   default: 44 when the current Object[] holds no mesh; else 41 for rpt_render_async, 43 for the blocking rpt_render;
  *       1 when the octree's children are not stored consecutively
- *   1   reads the reference's Octree/triangle layouts only (any valid octree)
- *   3   derived layouts, every object tested for every pixel (no culling), 4 waves per SIMD
- *   26  per-tile object masks from a prepass kernel (round 1's default), 5 waves per SIMD
- *   40, 41, 42  no prepass: every wavefront builds its own object mask from per-object image-plane rectangles
- *               (computed on the host in rpt_set_objects) with one lane-parallel test + __ballot; 4 / 5 / 6 waves per SIMD
- *   43          41 with the band of tile rows that holds the meshes dispatched first (dispatch order only; whole-frame contexts)
- *   44          41 without the octree walk compiled in (61 VGPRs, no scratch, 8 waves per SIMD): what frames without a mesh object
- *               get; asked for explicitly while Object[] holds a mesh, 41 is launched instead
+ *   1   reads the reference's Octree/triangle layouts only (any valid octree; no culling)
+ *   3   derived layouts, every object tested for every pixel, 5 waves per SIMD: the NO-CULL escape hatch, and the frame
+ *       rpt_verify_frame compares the culled kernels with
+ *   41  every wavefront builds its own object mask from per-object image-plane rectangles (computed on the host in
+ *       rpt_set_objects) with one lane-parallel test + __ballot, 5 waves per SIMD: what rpt_render_async launches
+ *   43  41 with the band of tile rows that holds the meshes dispatched first and triangle records asked for one iteration
+ *       ahead (whole-frame contexts): what the blocking rpt_render launches
+ *   44  41 without the octree walk compiled in (61 VGPRs, no scratch, 8 waves per SIMD): what frames without a mesh object
+ *       get; asked for explicitly while Object[] holds a mesh, 41 is launched instead
  *   50, 51      NOT bit-exact, opt-in only: 41 compiled with the arithmetic OpenCL C allows by default (fma contraction,
  *               2.5-ulp division, 3-ulp sqrt; csrc/rpt_relaxed.hip), 5 / 6 waves per SIMD.  Never chosen by variant 0.
- * The diagnostic kernels (7 loop counters, 8 primary rays only, 11 per-wave timeline) are not in the product library:
- * `make -C relativitypathtracer_amd/csrc diag` builds librpt_hip_diag.so with them (tools/divergence.py, tools/timeline.py). */
+ * Everything else — instrumented kernels (7 loop counters, 8 primary rays only, 11 per-wave timeline) and the measurement arms
+ * of rounds 1-3 (26 prepass masks, 40 / 42 other occupancies, 141 / 143 round 2's walk, 60-63 persistent workgroups with LDS
+ * staging and the per-workgroup ray queue, 256+ walk experiments) — is NOT in the product library:
+ * `make -C relativitypathtracer_amd/csrc diag` builds librpt_hip_diag.so with them (csrc/rpt_diag_kernels.hip.h). */
 int rpt_set_variant(rpt_ctx *ctx, int variant);
+
+/* A culled-vs-un-culled self-check on the device.  The default kernels drop objects per wavefront from conservatively
+ * sampled screen bounds and shadow rays per wavefront from segment-vs-box tests; a wrong bound would make an object vanish from
+ * a tile without any error.  rpt_verify_frame renders the context's CURRENT state (objects, parameters, rows) once with the
+ * kernel a frame would get (rpt_render_async's choice, or the variant set) and once with the un-culled kernel (3) into scratch
+ * buffers, compares the packed colours of every pixel on the device and returns the number of pixels that differ (0 = the cull
+ * changed nothing).  The context's framebuffer is not touched.  Cost: two frames + one reduction; meant for tests, soak runs and
+ * a host that wants to check a new kind of scene, not for every frame. */
+int rpt_verify_frame(rpt_ctx *ctx, unsigned long long *differing_pixels);
 
 /* The per-object cull record of the default kernel, exposed for tests (host code, needs no device): the rectangle
  * {u0, v0, u1, v1} on the camera's image plane z = 0.5 (pixel (x, y) of a W x H frame looks through

@@ -133,6 +133,7 @@ HIP_SYMBOLS = {
     "rpt_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "rpt_object_screen_rect": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rpt_object_screen_bounds": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "rpt_verify_frame": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rpt_render": (C.c_int, [C.c_void_p]),
     "rpt_render_async": (C.c_int, [C.c_void_p]),
     "rpt_sync": (C.c_int, [C.c_void_p]),
@@ -184,6 +185,26 @@ def _share_torch_hip_runtime():
                 C.CDLL(cand, mode=C.RTLD_GLOBAL)
             except OSError:
                 pass
+
+
+_hip_diag_lib = None
+
+
+def hip_diag() -> C.CDLL:
+    """Load librpt_hip_diag.so — the diagnostics build (`make -C relativitypathtracer_amd/csrc diag`): the product kernels plus
+    the instrumented ones and the measurement arms.  For tools/ and tests/test_gpu_diag_arms.py only; raises if it is missing."""
+    global _hip_diag_lib
+    if _hip_diag_lib is None:
+        p = _path("librpt_hip_diag.so")
+        if not os.path.exists(p):
+            raise RuntimeError(f"{p} is missing: build it with `make -C relativitypathtracer_amd/csrc diag`")
+        _share_torch_hip_runtime()
+        lib = C.CDLL(p)
+        for name, (res, args) in HIP_SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _hip_diag_lib = lib
+    return _hip_diag_lib
 
 
 def hip() -> C.CDLL:

@@ -243,8 +243,7 @@ RPT_DEV int octree_child_step(f3 &uv) {
 // Node<0>: the reference's 96-B nodes read field by field (a traversal step needs min/max,
 //          (trisIndex,trisCount), children[0], one children[k] and one neighbors[k], not the whole
 //          struct the reference copies).  Works for any valid octree.
-// Node<1>: the derived 64-B DNode + gathered DTri records (one dependent load per node, one per
-//          triangle).  Needs consecutive children, which the library checks at upload.
+// (The derived 64-B DNode + gathered DTri records are read by octree_walk below, record by record.)
 typedef float v4f __attribute__((ext_vector_type(4)));   // native vectors: one 16-B load, SROA-friendly
 typedef int v4i __attribute__((ext_vector_type(4)));
 template <int V> struct NodeRef;
@@ -269,44 +268,6 @@ template <> struct NodeRef<0> {
         v0v2 = C - A;
     }
 };
-
-template <> struct NodeRef<1> {
-    // the 64-B record as four 16-B loads held in scalars (no struct copy: keeps it in registers)
-    v4f lo, hi;         // min.xyz | firstChild , max.xyz | leafBegin   (ints carried as float bits)
-    v4i q2, q3;         // leafCount, nb[0..2] , nb[3..5], pad
-    RPT_DEV void load(const KernelArgs &a, int i) {
-        const v4f *p = reinterpret_cast<const v4f *>(a.dnodes + i);
-        lo = p[0];
-        hi = p[1];
-        q2 = reinterpret_cast<const v4i *>(p)[2];
-        q3 = reinterpret_cast<const v4i *>(p)[3];
-    }
-    RPT_DEV f3 bmin(const KernelArgs &) const { return mk3(lo.x, lo.y, lo.z); }
-    RPT_DEV f3 bmax(const KernelArgs &) const { return mk3(hi.x, hi.y, hi.z); }
-    RPT_DEV int link() const { return __float_as_int(lo.w); }
-    RPT_DEV bool is_leaf(const KernelArgs &) const { return link() == -1; }
-    RPT_DEV int child(const KernelArgs &, int k) const { return (link() & RPT_LINK_CHILD_MASK) + k; }
-    RPT_DEV int neighbor(const KernelArgs &, int side) const {   // select chain: no dynamic register indexing
-        int r = q2.y;
-        r = side == 1 ? q2.z : r;
-        r = side == 2 ? q2.w : r;
-        r = side == 3 ? q3.x : r;
-        r = side == 4 ? q3.y : r;
-        r = side == 5 ? q3.z : r;
-        return r;
-    }
-    RPT_DEV int tri_begin(const KernelArgs &) const { return __float_as_int(hi.w); }
-    RPT_DEV int tri_count(const KernelArgs &) const { return q2.x; }
-    RPT_DEV void tri(const KernelArgs &a, int k, f3 &A, f3 &v0v1, f3 &v0v2, int &id) const {
-        const v4f *p = reinterpret_cast<const v4f *>(a.dtris + k);
-        const v4f t0 = p[0], t1 = p[1], t2 = p[2];
-        A = mk3(t0.x, t0.y, t0.z);
-        v0v1 = mk3(t0.w, t1.x, t1.y);
-        v0v2 = mk3(t1.z, t1.w, t2.x);
-        id = __float_as_int(t2.y);
-    }
-};
-
 // opencl_kernel.cl:106-126 with the two edge vectors supplied
 RPT_DEV bool intersect_triangle_edges(f3 A, f3 v0v1, f3 v0v2, const Ray &ray, float &dist, f2 &uv) {
     const f3 pvec = cross(ray.dir, v0v2);
@@ -322,35 +283,6 @@ RPT_DEV bool intersect_triangle_edges(f3 A, f3 v0v1, f3 v0v2, const Ray &ray, fl
     dist = dot(v0v2, qvec) * invDet;
     return true;
 }
-
-// opencl_kernel.cl:256-308 from the point where the ray is in object space.  newRay = object-space
-// ray (direction normalised); world_origin/world_dirlen are ray->origin.yzw and |ray->dir.yzw|.
-// Diagnostic cycle accounting (V == 4 only): per wave, shader-clock cycles and wave-level iteration counts of
-// the three loops of the walk, accumulated in LDS by the first active lane.
-__shared__ unsigned long long rpt_diag_lds[4][8];
-template <int V>
-RPT_DEV void diag_add(int slot, unsigned long long v) {
-    if (V == 4) {
-        const unsigned long long m = __ballot(1);
-        if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) rpt_diag_lds[threadIdx.x >> 6][slot] += v;
-    }
-}
-template <int V>
-RPT_DEV unsigned long long diag_clock() { return V == 4 ? (unsigned long long)clock64() : 0ull; }
-
-// Diagnostic counting (V == 2 only): how many loop iterations lanes need vs. how many the wave executes.
-template <int V>
-RPT_DEV void count_iter(const KernelArgs &a, int which) {
-    if (V == 2) {
-        const unsigned long long m = __ballot(1);
-        const int lane = threadIdx.x & 63;
-        if (lane == __ffsll((long long)m) - 1) {
-            atomicAdd(&a.counters[which], (unsigned long long)__popcll(m));
-            atomicAdd(&a.counters[3 + which], 1ull);
-        }
-    }
-}
-
 // The walk's stop test (opencl_kernel.cl:283): length(exit point - origin) > hit.dist.  Until a triangle has been hit,
 // hit.dist is the caller's 1e20f, and sqrt(s) > 1e20f holds for no finite float s (sqrt(FLT_MAX) < 1.9e19), for s = +inf
 // only, and not for NaN: so while no lane of the wave has a hit the square root is not needed to decide it — same answer.
@@ -359,115 +291,10 @@ RPT_DEV bool exit_is_past_hit(f3 v, float hit_dist, bool didHit) {
     if (__ballot(didHit) == 0ull && hit_dist == 1e20f) return s == __builtin_inff();
     return __builtin_sqrtf(s) > hit_dist;
 }
-
-template <int V>
-RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin,
-                         float world_dirlen, Hit &hit) {
-    NodeRef<(V == 0 ? 0 : 1)> node;   // V >= 1: derived layouts (root = the mesh's root in THEIR numbering, DObj::root)
-    int currOctreeIndex = root;
-    node.load(a, currOctreeIndex);
-    f2 d;
-    int closeSide, farSide;
-    f3 nmin = node.bmin(a), nmax = node.bmax(a);
-    if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
-    f3 uv = newRay.origin + newRay.dir * d.x;
-
-    if (d.x < 0) {   // ray starts inside the root: descend to the leaf holding the origin
-        uv = (newRay.origin - nmin) / (nmax - nmin);
-        while (!node.is_leaf(a)) {
-            const int childIndex = V == 0 ? octree_child_step(uv) : octree_child_step_fast(uv);
-            currOctreeIndex = node.child(a, childIndex);
-            node.load(a, currOctreeIndex);
-        }
-        nmin = node.bmin(a);
-        nmax = node.bmax(a);
-        if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
-        uv = newRay.origin + newRay.dir * d.x;
-    }
-
-    const ExitPlan plan = makeExitPlan(normalize(newRay.dir / (nmax - nmin)));
-    bool didHit = false;
-    int hitTri = 0;
-    int steps = 0;
-    while (currOctreeIndex != -1) {
-        if (++steps > RPT_MAX_LEAF_STEPS) break;
-        count_iter<V>(a, 0);
-        if (V == 2) {   // diagnostic: how many DIFFERENT nodes do the active lanes of this wave stand in right now?
-            unsigned long long todo = __ballot(1);
-            const unsigned long long all = todo;
-            int distinct = 0;
-            while (todo) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const int n0 = __shfl(currOctreeIndex, leader);
-                todo &= ~__ballot(currOctreeIndex == n0);
-                distinct++;
-            }
-            if ((int)(threadIdx.x & 63) == __ffsll((long long)all) - 1) {
-                atomicAdd(&a.counters[8], (unsigned long long)distinct);
-                atomicAdd(&a.counters[9], (unsigned long long)__popcll(all));
-                atomicAdd(&a.counters[10 + (distinct <= 1 ? 0 : distinct <= 2 ? 1 : distinct <= 4 ? 2 : distinct <= 8 ? 3 : distinct <= 16 ? 4 : 5)], 1ull);
-            }
-        }
-        const unsigned long long t_leaf0 = diag_clock<V>();
-        node.load(a, currOctreeIndex);
-        nmin = node.bmin(a);
-        nmax = node.bmax(a);
-        uv = (uv - nmin) / (nmax - nmin);
-        bool descended = false;
-        const unsigned long long t_desc0 = diag_clock<V>();
-        while (!node.is_leaf(a)) {
-            const int childIndex = V == 0 ? octree_child_step(uv) : octree_child_step_fast(uv);
-            currOctreeIndex = node.child(a, childIndex);
-            node.load(a, currOctreeIndex);
-            descended = true;
-            count_iter<V>(a, 2);
-            diag_add<V>(3, 1);
-        }
-        const unsigned long long t_tri0 = diag_clock<V>();
-        diag_add<V>(2, t_tri0 - t_desc0);
-        if (descended) {
-            nmin = node.bmin(a);
-            nmax = node.bmax(a);
-        }
-        const int trisIndex = node.tri_begin(a);
-        const int trisEnd = trisIndex + node.tri_count(a);
-        for (int i = trisIndex; i < trisEnd; i++) {
-            f3 A, v0v1, v0v2;
-            int tri;
-            node.tri(a, i, A, v0v1, v0v2, tri);
-            count_iter<V>(a, 1);
-            diag_add<V>(1, 1);
-            float dist;
-            f2 triUV;
-            if (intersect_triangle_edges(A, v0v1, v0v2, newRay, dist, triUV)) {
-                if (0 <= dist && dist < hit.dist) {
-                    hitTri = tri;
-                    hit.dist = dist;
-                    hit.uv = triUV;
-                    didHit = true;
-                }
-            }
-        }
-        const unsigned long long t_tri1 = diag_clock<V>();
-        diag_add<V>(0, t_tri1 - t_tri0);
-        const f3 extents = nmax - nmin;
-        farSide = getOppositeBoxSide(plan, uv);
-        uv = nmin + uv * extents;
-        // (derived layout: the neighbour index is READ when the leaf is left — one more L1 hit per leaf step — instead of all six
-        // being held in registers through the triangle loop: 28 -> 12 B of scratch at 5 waves per SIMD, 100 -> 80 B at 6;
-        // bunny 4K 0.0958 -> 0.0935 ms per frame in flight)
-        currOctreeIndex = V == 0 ? node.neighbor(a, farSide) : a.dnodes[currOctreeIndex].nb[farSide];
-        const bool stop = exit_is_past_hit(uv - newRay.origin, hit.dist, didHit);
-        diag_add<V>(4, (diag_clock<V>() - t_tri1) + (t_desc0 - t_leaf0));
-        diag_add<V>(5, 1);
-        if (stop) break;
-    }
-    if (V == 2) {   // diagnostic: longest single walk (leaf steps) and a coarse histogram of walk lengths
-        atomicMax(&a.counters[6], (unsigned long long)steps);
-        if (steps > 32) atomicAdd(&a.counters[7], 1ull);
-    }
-    if (!didHit) return false;
-
+// opencl_kernel.cl:287-306: normal, texture coordinates and the distance re-measured in the caller's frame, from the walk's
+// closest triangle (hit.dist parametric, hit.uv barycentric on entry)
+RPT_DEV void mesh_hit_finish(const KernelArgs &a, const rpt_object &obj, f3 origin, f3 dir, int hitTri, f3 world_origin,
+                             float world_dirlen, Hit &hit) {
     const float u = hit.uv.x, v = hit.uv.y;
     const float w = 1.0f - u - v;
     const f3 normA = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 0]]);
@@ -479,19 +306,93 @@ RPT_DEV bool octree_core(const KernelArgs &a, const rpt_object &obj, int root, c
     const rpt_float2 uvC = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 2]];
     hit.uv.x = w * uvA.x + u * uvB.x + v * uvC.x;
     hit.uv.y = w * uvA.y + u * uvB.y + v * uvC.y;
-    const f3 objPoint = newRay.origin + newRay.dir * hit.dist;
+    const f3 objPoint = origin + dir * hit.dist;
     const f3 worldPoint = transformPoint(obj.M, objPoint);
     hit.dist = length(worldPoint - world_origin) / world_dirlen;
+}
+
+// opencl_kernel.cl:200-308 on the reference's own layouts (any valid octree; the fallback kernel, variant 1): from the point
+// where the ray is in object space.  newRay = object-space ray (direction normalised); world_origin/world_dirlen are
+// ray->origin.yzw and |ray->dir.yzw|.
+RPT_DEV bool octree_core_ref(const KernelArgs &a, const rpt_object &obj, const Ray &newRay, f3 world_origin, float world_dirlen, Hit &hit) {
+    NodeRef<0> node;
+    int currOctreeIndex = obj.meshIndex;
+    node.load(a, currOctreeIndex);
+    f2 d;
+    int closeSide, farSide;
+    f3 nmin = node.bmin(a), nmax = node.bmax(a);
+    if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
+    f3 uv = newRay.origin + newRay.dir * d.x;
+    if (d.x < 0) {   // ray starts inside the root: descend to the leaf holding the origin
+        uv = (newRay.origin - nmin) / (nmax - nmin);
+        while (!node.is_leaf(a)) {
+            currOctreeIndex = node.child(a, octree_child_step(uv));
+            node.load(a, currOctreeIndex);
+        }
+        nmin = node.bmin(a);
+        nmax = node.bmax(a);
+        if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
+        uv = newRay.origin + newRay.dir * d.x;
+    }
+    const ExitPlan plan = makeExitPlan(normalize(newRay.dir / (nmax - nmin)));
+    bool didHit = false;
+    int hitTri = 0;
+    int steps = 0;
+    while (currOctreeIndex != -1) {
+        if (++steps > RPT_MAX_LEAF_STEPS) break;
+        node.load(a, currOctreeIndex);
+        nmin = node.bmin(a);
+        nmax = node.bmax(a);
+        uv = (uv - nmin) / (nmax - nmin);
+        while (!node.is_leaf(a)) {
+            currOctreeIndex = node.child(a, octree_child_step(uv));
+            node.load(a, currOctreeIndex);
+            nmin = node.bmin(a);
+            nmax = node.bmax(a);
+        }
+        const int trisIndex = node.tri_begin(a);
+        const int trisEnd = trisIndex + node.tri_count(a);
+        for (int i = trisIndex; i < trisEnd; i++) {
+            f3 A, v0v1, v0v2;
+            int tri;
+            node.tri(a, i, A, v0v1, v0v2, tri);
+            float dist;
+            f2 triUV;
+            if (intersect_triangle_edges(A, v0v1, v0v2, newRay, dist, triUV)) {
+                if (0 <= dist && dist < hit.dist) {
+                    hitTri = tri;
+                    hit.dist = dist;
+                    hit.uv = triUV;
+                    didHit = true;
+                }
+            }
+        }
+        const f3 extents = nmax - nmin;
+        farSide = getOppositeBoxSide(plan, uv);
+        uv = nmin + uv * extents;
+        currOctreeIndex = node.neighbor(a, farSide);
+        if (exit_is_past_hit(uv - newRay.origin, hit.dist, didHit)) break;
+    }
+    if (!didHit) return false;
+    mesh_hit_finish(a, obj, newRay.origin, newRay.dir, hitTri, world_origin, world_dirlen, hit);
     return true;
 }
 
-// ---- the same walk with its memory round trips re-ordered (V >= 256: flags in the low bits; results cannot differ: only WHEN
-// a record is asked for changes, never what is computed from it) -------------------------------------------------------------
-//   1: the exit face of a leaf does not depend on its triangles (getOppositeBoxSide works on the ray and the entry point alone),
-//      so it is found BEFORE the triangle loop and the neighbour's index is on its way while the triangles are tested
-//   2: ... and once that index is there (after the first triangle), so is the neighbour's record: the next leaf step starts with
-//      its node already in registers
-//   4: triangle records are asked for one iteration ahead
+// ---- the walk on the derived layouts (what ships) -------------------------------------------------------------------------
+// opencl_kernel.cl:200-308 once more, arithmetic unchanged; what is organised for the machine is WHEN memory is asked for — a
+// leaf step of the reference's loop is a chain of dependent round trips (node, one per descent level, one per triangle, the
+// neighbour), and with five waves on a SIMD the waves wait on exactly that chain (profiles/r02_*_pmc_summary.json: half of their
+// life), so the chain is made shorter, not the traffic smaller:
+//   * a node is read as ONE 64-B record (box, link, first triangle, count), a triangle as one 40-B record (A, B-A, C-A, id);
+//   * a descent reads 4 bytes per level from the compact link array, and the parent's link says which children are leaves, so no
+//     level is spent on finding that out;
+//   * the exit face of a leaf does not depend on its triangles (getOppositeBoxSide works on the ray and the entry point alone):
+//     it is found BEFORE the triangle loop, and the neighbour's index travels while the triangles are tested;
+//   * PIPELINE (the blocking call's kernel, whose frame is as long as its longest wave): triangle records are asked for one
+//     iteration ahead.  Ten more live registers: 40 B of scratch at five waves per SIMD, worth it for latency (bunny 4K one
+//     frame at a time 0.196 -> 0.191 ms, 1080p 0.166 -> 0.158), not for throughput (0.090 -> 0.096 ms per frame in flight).
+// Measured against round 2's walk (profiles/r03_walk_ab.txt): bunny 4K 0.0949 -> 0.0903 ms per frame in flight, 0.201 -> 0.191
+// one at a time; zero scratch instead of 12 B.  What was tried on top and lost is in the diagnostics build (rpt_diag_walks.hip.h).
 struct NodeRec { v4f lo, hi; int count; };
 RPT_DEV NodeRec load_node_rec(const KernelArgs &a, int i) {
     const v4f *p = reinterpret_cast<const v4f *>(a.dnodes + i);
@@ -525,9 +426,21 @@ RPT_DEV void test_tri_rec(const TriRec &r, const Ray &ray, Hit &hit, int &hitTri
     }
 }
 
-template <int F>
-RPT_DEV bool octree_core_v2(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin,
-                            float world_dirlen, Hit &hit) {
+// from an inner node (link != -1) down to the leaf that holds uv (opencl_kernel.cl:256-261: the same child steps)
+RPT_DEV int descend_to_leaf(const KernelArgs &a, int link, f3 &uv) {
+    int idx;
+    for (;;) {
+        const int k = octree_child_step_fast(uv);
+        idx = (link & RPT_LINK_CHILD_MASK) + k;
+        if ((link >> (24 + k)) & 1) break;          // the link says this child is a leaf: no lookup
+        link = a.links[idx];
+    }
+    return idx;
+}
+
+template <bool PIPELINE>
+RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin,
+                         float world_dirlen, Hit &hit) {
     int curr = root;
     NodeRec rec = load_node_rec(a, curr);
     f2 d;
@@ -535,14 +448,10 @@ RPT_DEV bool octree_core_v2(const KernelArgs &a, const rpt_object &obj, int root
     f3 nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z), nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
     if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
     f3 uv = newRay.origin + newRay.dir * d.x;
-    if (d.x < 0) {
+    if (d.x < 0) {   // ray starts inside the root: descend to the leaf holding the origin
         uv = (newRay.origin - nmin) / (nmax - nmin);
         if (__float_as_int(rec.lo.w) != -1) {
-            int link = __float_as_int(rec.lo.w);
-            while (link != -1) {
-                curr = (link & RPT_LINK_CHILD_MASK) + octree_child_step_fast(uv);
-                link = a.dnodes[curr].link;
-            }
+            curr = descend_to_leaf(a, __float_as_int(rec.lo.w), uv);
             rec = load_node_rec(a, curr);
         }
         nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
@@ -557,70 +466,53 @@ RPT_DEV bool octree_core_v2(const KernelArgs &a, const rpt_object &obj, int root
         nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
         nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
         uv = (uv - nmin) / (nmax - nmin);
-        int link = __float_as_int(rec.lo.w);
-        if (link != -1) {
-            while (link != -1) {
-                const int k = octree_child_step_fast(uv);
-                curr = (link & RPT_LINK_CHILD_MASK) + k;
-                if ((F & 16) && ((link >> (24 + k)) & 1)) break;          // the link says this child is a leaf: no lookup
-                link = (F & 16) ? a.links[curr] : a.dnodes[curr].link;
-            }
+        if (__float_as_int(rec.lo.w) != -1) {
+            curr = descend_to_leaf(a, __float_as_int(rec.lo.w), uv);
             rec = load_node_rec(a, curr);
             nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
             nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
         }
         int i = __float_as_int(rec.hi.w);
         const int trisEnd = i + rec.count;
-        // the way out, before the triangles
-        farSide = getOppositeBoxSide(plan, uv);
+        farSide = getOppositeBoxSide(plan, uv);             // the way out, before the triangles
         const int next = a.dnodes[curr].nb[farSide];
-        NodeRec nrec;
-        nrec.lo = nrec.hi = rec.lo;
-        nrec.count = 0;
-        if (F & 4) {
+        if (PIPELINE) {
             if (i < trisEnd) {
                 TriRec cur = load_tri_rec(a, i);
-                bool fetched = false;
                 for (; i < trisEnd; i++) {
                     TriRec nxt = cur;
                     if (i + 1 < trisEnd) nxt = load_tri_rec(a, i + 1);
                     test_tri_rec(cur, newRay, hit, hitTri, didHit);
-                    if ((F & 2) && !fetched) { if (next != -1) nrec = load_node_rec(a, next); fetched = true; }
                     cur = nxt;
                 }
-            } else if (F & 2) {
-                if (next != -1) nrec = load_node_rec(a, next);
             }
         } else {
-            if (i < trisEnd) {
-                test_tri_rec(load_tri_rec(a, i), newRay, hit, hitTri, didHit);
-                i++;
-            }
-            if (F & 2) { if (next != -1) nrec = load_node_rec(a, next); }
             for (; i < trisEnd; i++) test_tri_rec(load_tri_rec(a, i), newRay, hit, hitTri, didHit);
         }
         uv = nmin + uv * (nmax - nmin);
-        const bool stop = exit_is_past_hit(uv - newRay.origin, hit.dist, didHit);
-        if (stop || next == -1) break;
+        if (exit_is_past_hit(uv - newRay.origin, hit.dist, didHit) || next == -1) break;
         curr = next;
-        rec = (F & 2) ? nrec : load_node_rec(a, curr);
+        rec = load_node_rec(a, curr);
     }
     if (!didHit) return false;
-    const float u = hit.uv.x, v = hit.uv.y;
-    const float w = 1.0f - u - v;
-    const f3 normA = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 0]]);
-    const f3 normB = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 1]]);
-    const f3 normC = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 2]]);
-    hit.normal = normalize(applyTranspose(obj.InvM, normA * w + normB * u + normC * v));
-    const rpt_float2 uvA = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 0]];
-    const rpt_float2 uvB = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 1]];
-    const rpt_float2 uvC = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 2]];
-    hit.uv.x = w * uvA.x + u * uvB.x + v * uvC.x;
-    hit.uv.y = w * uvA.y + u * uvB.y + v * uvC.y;
-    const f3 objPoint = newRay.origin + newRay.dir * hit.dist;
-    const f3 worldPoint = transformPoint(obj.M, objPoint);
-    hit.dist = length(worldPoint - world_origin) / world_dirlen;
+    mesh_hit_finish(a, obj, newRay.origin, newRay.dir, hitTri, world_origin, world_dirlen, hit);
     return true;
+}
+
+#ifdef RPT_DIAGNOSTICS
+}  // namespace rptd
+#include "rpt_diag_walks.hip.h"      /* librpt_hip_diag.so only: round 2's walk with its instrumentation, the experiment arms */
+namespace rptd {
+#endif
+
+// Which walk a kernel variant uses.  V = 0: the reference's layouts; V = 23 (the blocking call's kernel): the pipelined form.
+template <int V>
+RPT_DEV bool mesh_walk(const KernelArgs &a, const rpt_object &obj, int i, const Ray &newRay, f3 world_origin, float world_dirlen, Hit &hit) {
+#ifdef RPT_DIAGNOSTICS
+    if (diag_walk_selected<V>()) return diag_walk<V>(a, obj, a.dobjs[i].root, newRay, world_origin, world_dirlen, hit);
+#endif
+    if (V == 0) return octree_core_ref(a, obj, newRay, world_origin, world_dirlen, hit);
+    return octree_walk<V == 23>(a, obj, a.dobjs[i].root, newRay, world_origin, world_dirlen, hit);
 }
 
 RPT_DEV float max3(f3 v) { return cl_max(cl_max(v.x, v.y), v.z); }   // opencl_kernel.cl:310
@@ -735,8 +627,7 @@ RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, H
         Ray newRay;
         newRay.origin = origin;
         newRay.dir = dir;
-        if (V >= 256) return octree_core_v2<(V & 23)>(a, obj, a.dobjs[i].root, newRay, yzw(origin4), length(yzw(dir4)), hit);
-        return octree_core<V>(a, obj, V == 0 ? obj.meshIndex : a.dobjs[i].root, newRay, yzw(origin4), length(yzw(dir4)), hit);
+        return mesh_walk<V>(a, obj, i, newRay, yzw(origin4), length(yzw(dir4)), hit);
     }
     default:
         return false;
@@ -766,8 +657,7 @@ RPT_DEV bool intersect_object_primary(const KernelArgs &a, int i, f4 rayDir, Hit
         newRay.origin = origin;
         newRay.dir = dir;
         const f3 cam3 = mk3(obj.stationaryCam.y, obj.stationaryCam.z, obj.stationaryCam.w);
-        if (V >= 256) return octree_core_v2<(V & 23)>(a, obj, pre.root, newRay, cam3, length(d3), hit);
-        return octree_core<V>(a, obj, pre.root, newRay, cam3, length(d3), hit);
+        return mesh_walk<V>(a, obj, i, newRay, cam3, length(d3), hit);
     }
     default:
         return false;
@@ -857,10 +747,12 @@ RPT_DEV bool trace(const KernelArgs &a, f3 camdir, unsigned long long object_mas
         }
     }
     if (hit.object < 0) return false;
-    if (V == 3) {   // diagnostic: stop after the closest hit (timing of the primary walk alone; not a product path)
+#ifdef RPT_DIAGNOSTICS
+    if (V == 5) {   // stop after the closest hit (timing of the primary walk alone)
         color_out = mk3(hit.dist, hit.normal.x + hit.uv.x, hit.normal.y + hit.normal.z + hit.uv.y);
         return true;
     }
+#endif
 
     const rpt_object &ho = a.objects[hit.object];
     f3 hcolor = ho.textureIndex != -1 ? sample_texture(a, ho, hit.uv) : ld3(ho.color);
@@ -968,26 +860,27 @@ RPT_DEV unsigned long long wave_object_mask(const KernelArgs &a, int tile_x0, in
     return __ballot(keep);
 }
 
+template <int V> RPT_DEV constexpr bool culled_variant() { return V >= 20; }
+template <int V> RPT_DEV constexpr bool band_first_variant() { return V == 23 || V == 123 || (V >= 256 && V < 1000 && (V & 8)); }
+
 // ---------------------------------------------------------------------------------------------
 // One thread per pixel, wave = 8x8 tile, workgroup = 32x8 strip.
-//   V = 0: reads the reference layouts only (general fallback, any valid octree)
-//   V = 1: derived DNode/DTri/DObj layouts
-//   V = 2, 3, 4: diagnostic builds (loop counters, primary rays only, per-wave timeline; -DRPT_DIAGNOSTICS only)
-//   V = 10: per-tile object masks from the prepass kernel (round 1's default, kept for A/B)
-//   V = 20: the wave's object mask from per-object image-plane rectangles + __ballot (the default)
+//   V = 0: reads the reference layouts only (general fallback, any valid octree; no culling)
+//   V = 1: derived layouts, every object tested for every pixel (the un-culled form rpt_verify_frame compares with)
+//   V = 20: derived layouts + the wave's object mask from per-object image-plane rectangles + __ballot (rpt_render_async)
+//   V = 23: 20 with the band of tile rows that holds the meshes dispatched first and the pipelined walk (the blocking rpt_render)
+//   V = 24: 20 without the octree walk compiled in (frames whose Object[] holds no mesh)
+//   other values: diagnostics build only (rpt_diag_kernels.hip.h)
 template <int V>
 RPT_DEV void render_pixel_body(const KernelArgs &a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    unsigned long long t_start = 0;
-    if (V == 4) {
-        t_start = wall_clock64();
-        if ((threadIdx.x & 63) < 8) rpt_diag_lds[threadIdx.x >> 6][threadIdx.x & 63] = 0;
-        rpt_diag_lds[threadIdx.x >> 6][6] = clock64();
-    }
+#ifdef RPT_DIAGNOSTICS
+    const DiagWaveClock diag_clock0 = diag_wave_begin<V>();
+#endif
     int tile_row = (int)blockIdx.y;              // 8-row tiles of this context, natural order
-    int strip = (int)blockIdx.x;                 // 32-pixel-wide strip of that row
-    if ((V == 23 || (V >= 256 && (V & 8))) && a.first_h > 0) {
+    const int strip = (int)blockIdx.x;           // 32-pixel-wide strip of that row
+    if (band_first_variant<V>() && a.first_h > 0) {
         // Workgroups are handed out in the order of their linear index, i.e. row of strips by row of strips.  One frame at a
         // time, what ends the frame is the last of its long waves, so the band of tile rows that holds the meshes goes first
         // (whole rows, in their natural order: neighbours stay neighbours) and the other rows follow in order.
@@ -1002,18 +895,17 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
     // the wave's object mask comes from a __ballot over ALL 64 lanes (lane i answers for object i), so it is formed
     // before the lanes of a partial tile leave
     unsigned long long object_mask = ~0ull;
-    if (V >= 20) object_mask = wave_object_mask(a, strip * 32 + wave * 8, global_tile * RPT_TILE_ROWS);
+    if (culled_variant<V>()) object_mask = wave_object_mask(a, strip * 32 + wave * 8, global_tile * RPT_TILE_ROWS);
+#ifdef RPT_DIAGNOSTICS
+    if (V == 10) object_mask = a.tile_masks[__builtin_amdgcn_readfirstlane(tile_row * a.mask_tiles_x + (int)blockIdx.x * 4 + wave)];   // the prepass's per-tile mask
+#endif
     if (x_coord >= a.width || y_coord >= a.height) return;   // the reference has no guard (UB)
 
     f3 color;
     f3 mapped = mk3(0.0f, 0.0f, 0.0f);
     bool traced = false;
     uint32_t packed = a.bg_packed;
-    if (V == 10) {   // per-tile object mask of the prepass
-        const int tile = __builtin_amdgcn_readfirstlane(tile_row * a.mask_tiles_x + (int)blockIdx.x * 4 + wave);
-        object_mask = a.tile_masks[tile];
-    }
-    const bool masked = V == 10 || V >= 20;
+    const bool masked = culled_variant<V>() || V == 10;
     if (!masked || object_mask != 0 || a.object_count > 64) {
         const f3 camdir = createCamRayDir((float)x_coord, (float)y_coord, a.width, a.height, a.aspect);
         if (trace<V>(a, camdir, object_mask, color)) {
@@ -1023,14 +915,10 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
     }
 
     const size_t id = (size_t)y_coord * a.width + x_coord;
-    if (a.out16) {
-        uint4 px;
-        px.x = __float_as_uint((float)x_coord);
-        px.y = __float_as_uint((float)y_coord);
-        px.z = packed;
-        px.w = 0u;
-        store_pixel(a.out16, id, px.x, px.y, px.z, px.w);
-    }
+#ifdef RPT_DIAGNOSTICS
+    if (V == 785 && object_mask == 0ull) return;      // EXPERIMENT (wrong image): what do the sky tiles' stores cost the walks?
+#endif
+    if (a.out16) store_pixel(a.out16, id, __float_as_uint((float)x_coord), __float_as_uint((float)y_coord), packed, 0u);
     // (the 4-byte plane likewise: measured against the default policy on a rank's share of the frame, bunny 4K 0.0581 -> 0.0566 ms, shadows the same)
     if (a.plane) __builtin_nontemporal_store(packed, a.plane + (size_t)local_row * a.width + x_coord);
     if (a.debug_rgb) {
@@ -1039,120 +927,28 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
         a.debug_rgb[3 * id + 1] = mapped.y;
         a.debug_rgb[3 * id + 2] = mapped.z;
     }
-    if (V == 4 && a.wave_times) {
-        const unsigned long long t_end = wall_clock64();
-        const unsigned long long m = __ballot(1);
-        if (lane == __ffsll((long long)m) - 1) {
-            const size_t w = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
-            a.wave_times[10 * w] = t_start;
-            a.wave_times[10 * w + 1] = t_end;
-            rpt_diag_lds[wave][7] = clock64();
-            for (int q = 0; q < 8; q++) a.wave_times[10 * w + 2 + q] = rpt_diag_lds[wave][q];
-        }
-    }
+#ifdef RPT_DIAGNOSTICS
+    diag_wave_end<V>(a, diag_clock0);
+#endif
 }
 
 #ifndef RPT_RELAXED_FP    /* rpt_relaxed.hip instantiates its own two kernels and nothing else from here on */
-// Product kernels (rpt_set_variant): the default, the general fallback and the A/B forms kept for measurement.
-__global__ __launch_bounds__(256) void rpt_render_kernel_v0(const KernelArgs a) { render_pixel_body<0>(a); }                                                            // 1
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_w4(const KernelArgs a) { render_pixel_body<1>(a); }           // 3
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_v1_masked_w5(const KernelArgs a) { render_pixel_body<10>(a); }   // 26
-// V = 20: the wave's object mask from the per-object screen rectangles by lane-parallel test + __ballot (no prepass)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_ballot_w4(const KernelArgs a) { render_pixel_body<20>(a); }       // 40
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_w5(const KernelArgs a) { render_pixel_body<20>(a); }       // 41 = default
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_ballot_w6(const KernelArgs a) { render_pixel_body<20>(a); }       // 42
-// V = 24: the same without the octree walk compiled in, for frames whose Object[] holds no mesh: 61 VGPRs, no scratch, EIGHT waves
-// per SIMD (the walk is what needs 96 registers).  arch 1080p 0.0370 -> 0.0301 ms per frame in flight, cubes.txt 4K 0.0898 -> 0.0725.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_analytic_w8(const KernelArgs a) { render_pixel_body<24>(a); }     // 44
-// V = 23: 20 + the strips that hold the meshes handed out first (dispatch order only)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_first_w5(const KernelArgs a) { render_pixel_body<23>(a); }   // 43
-// experiment arms of round 3 (walk with re-ordered round trips): 257, 259, 261, 263 (+8: mesh band first)
-#define RPT_X_KERNEL(N) __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_x##N(const KernelArgs a) { render_pixel_body<N>(a); }
-#define RPT_XW_KERNEL(N, W) __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) void rpt_render_kernel_x##N##_w##W(const KernelArgs a) { render_pixel_body<N>(a); }
-RPT_XW_KERNEL(257, 6) RPT_XW_KERNEL(257, 4) RPT_XW_KERNEL(263, 4) RPT_XW_KERNEL(259, 4) RPT_X_KERNEL(273) RPT_X_KERNEL(277)
-RPT_X_KERNEL(256) RPT_X_KERNEL(257) RPT_X_KERNEL(259) RPT_X_KERNEL(261) RPT_X_KERNEL(263) RPT_X_KERNEL(265) RPT_X_KERNEL(269)
-#ifdef RPT_DIAGNOSTICS   /* librpt_hip_diag.so only (make diag): loop counters, primary rays only, per-wave timeline */
-__global__ __launch_bounds__(256) void rpt_render_kernel_v1_diag(const KernelArgs a) { render_pixel_body<2>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void rpt_render_kernel_v1_timeline(const KernelArgs a) { render_pixel_body<4>(a); }
-__global__ __launch_bounds__(256) void rpt_render_kernel_primary_only(const KernelArgs a) { render_pixel_body<3>(a); }
+// Product kernels (rpt_set_variant; the number in the comment is the variant).
+__global__ __launch_bounds__(256) void rpt_render_kernel_v0(const KernelArgs a) { render_pixel_body<0>(a); }                                                              // 1: any valid octree
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_unculled_w5(const KernelArgs a) { render_pixel_body<1>(a); }         // 3: no cull (rpt_verify_frame; the escape hatch)
+// the wave's object mask from the per-object screen rectangles by lane-parallel test + __ballot, 5 waves per SIMD (96 VGPRs, no scratch)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_w5(const KernelArgs a) { render_pixel_body<20>(a); }          // 41 = rpt_render_async
+// the same with the tile rows that hold the meshes dispatched first and the pipelined walk (40 B of scratch): latency, not throughput
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_first_w5(const KernelArgs a) { render_pixel_body<23>(a); }    // 43 = the blocking rpt_render
+// without the octree walk compiled in, for frames whose Object[] holds no mesh: 61 VGPRs, no scratch, EIGHT waves per SIMD
+// (arch 1080p 0.0370 -> 0.0301 ms per frame in flight, cubes.txt 4K 0.0898 -> 0.0725)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_analytic_w8(const KernelArgs a) { render_pixel_body<24>(a); }        // 44
+
+#ifdef RPT_DIAGNOSTICS
+}  // namespace rptd
+#include "rpt_diag_kernels.hip.h"    /* librpt_hip_diag.so only: instrumented kernels, round 1's prepass, the A/B arms of rounds 2 and 3 */
+namespace rptd {
 #endif
-
-// ---------------------------------------------------------------------------------------------
-// Tile-mask prepass (one thread per 8x8 tile).  For every object it asks whether ANY primary ray
-// of the tile can reach the object's bounding sphere: the tile's rays (object space) lie in a cone
-// around the centre ray whose half-angle is taken from the four corner rays (of the tile grown by
-// half a pixel) with a 1.5x safety factor; the sphere subtends asin(r/d) around the direction to its
-// centre; the object is dropped for the tile only if the two cones are clearly disjoint.  Radii are
-// inflated on the host and every doubtful case (origin inside or near the sphere, degenerate or
-// non-finite directions, wide tiles) keeps the object.  The arithmetic here is approximate on
-// purpose: it only decides which exact tests are skipped, and a skipped test is one the reference
-// would have failed for every pixel of the tile.
-RPT_DEV f3 cull_dir(const DObj &o, f3 nd) {
-    return mk3(o.B[0] * nd.x + o.B[1] * nd.y + o.B[2] * nd.z + o.b[0],
-               o.B[3] * nd.x + o.B[4] * nd.y + o.B[5] * nd.z + o.b[1],
-               o.B[6] * nd.x + o.B[7] * nd.y + o.B[8] * nd.z + o.b[2]);
-}
-
-__global__ __launch_bounds__(256) void rpt_tile_bin_kernel(const KernelArgs a) {
-    const int tile = blockIdx.x * 256 + threadIdx.x;
-    const bool valid = tile < a.n_tiles;
-    unsigned long long mask = 0;
-    if (valid) {
-        const int tx = tile % a.mask_tiles_x, trow = tile / a.mask_tiles_x;
-        const float x0 = (float)(tx * 8);
-        const float y0 = (float)(((trow >> a.run_log2) * a.tile_step + a.first_tile + (trow & ((1 << a.run_log2) - 1))) * RPT_TILE_ROWS);
-        const float xs[5] = {x0 + 3.5f, x0 - 0.5f, x0 + 7.5f, x0 - 0.5f, x0 + 7.5f};
-        const float ys[5] = {y0 + 3.5f, y0 - 0.5f, y0 - 0.5f, y0 + 7.5f, y0 + 7.5f};
-        f3 nd[5];
-        for (int k = 0; k < 5; k++) {
-            const f3 p = mk3((xs[k] / (float)a.width - 0.5f) * a.aspect, ys[k] / (float)a.height - 0.5f, 0.5f);
-            nd[k] = p * (1.0f / __builtin_sqrtf(dot(p, p)));
-        }
-        const int n = a.object_count < 64 ? a.object_count : 64;
-        for (int i = 0; i < n; i++) {
-            const DObj &o = a.dobjs[i];
-            bool keep = true;
-            if (o.rb >= 0.0f) {
-                f3 u[5];
-                float lmin = 3.0e38f, lmax = 0.0f;
-                for (int k = 0; k < 5; k++) {
-                    const f3 d = cull_dir(o, nd[k]);
-                    const float l = __builtin_sqrtf(dot(d, d));
-                    lmin = l < lmin ? l : lmin;
-                    lmax = l > lmax ? l : lmax;
-                    u[k] = d * (1.0f / l);
-                }
-                // Angles through their SINES, |u x v| (accurate for the tiny angles that strongly anisotropic object
-                // scales produce; acos of a cosine near 1 loses them in fp32), and bounded instead of evaluated:
-                // for an angle below 0.5 rad, sin <= angle <= 1.05 sin.  The tile's half-angle and the sphere's
-                // angular radius are over-estimated, the angle to the sphere's centre is under-estimated.
-                float sTile = 0.0f;
-                bool tile_ok = true;
-                for (int k = 1; k < 5; k++) {
-                    const f3 cr = cross(u[0], u[k]);
-                    const float sn = __builtin_sqrtf(dot(cr, cr));
-                    sTile = sn > sTile ? sn : sTile;
-                    tile_ok = tile_ok && dot(u[0], u[k]) > 0.0f;
-                }
-                const float thTile = 1.05f * sTile;                 // >= the true half-angle while sTile < 0.47
-                const f3 to = mk3(o.cbx - o.ox, o.cby - o.oy, o.cbz - o.oz);
-                const float dist = __builtin_sqrtf(dot(to, to));
-                const bool sane = tile_ok && (sTile < 0.2f) && (lmin > 0.05f * lmax) && (lmax < 1.0e30f) && (dist > 1.05f * o.rb) && (dist < 1.0e30f);
-                if (sane) {
-                    const f3 ca = cross(u[0], to);
-                    const float sinAng = __builtin_sqrtf(dot(ca, ca)) / dist;
-                    const float angLow = dot(u[0], to) > 0.0f ? sinAng : 1.0f;   // angle >= its sine; behind: >= pi/2 > 1
-                    const float xs_ = o.rb / dist;
-                    const float thObj = xs_ < 0.45f ? 1.05f * xs_ : asinf(fminf(xs_, 1.0f));   // asin(x) <= 1.05 x below 0.45; near objects pay for the asin
-                    keep = !(angLow > thObj + 1.5f * thTile + 1.0e-4f);     // NaN anywhere -> keep
-                }
-            }
-            if (keep) mask |= 1ull << i;
-        }
-        if (a.object_count > 64) mask |= 0ull;   // objects >= 64 are never culled (trace() tests them always)
-        a.tile_masks[tile] = mask;
-    }
-}
 
 // Root-side reassembly after the gather: plane of rank r, local tile k -> global tile r + k*n_ranks.
 __global__ __launch_bounds__(256) void rpt_scatter_plane_kernel(const uint32_t *planes, rpt_pixel *out16, int width,
@@ -1222,6 +1018,13 @@ __global__ __launch_bounds__(256) void rpt_scatter_helper_planes3_kernel(const u
     px.z = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | (1u << 24);
     px.w = 0u;
     store_pixel(out16, (size_t)y * width + x, px.x, px.y, px.z, px.w);
+}
+
+// rpt_verify_frame: how many packed colours differ between two colour planes (one ballot + popcount per wave-iteration)
+__global__ __launch_bounds__(256) void rpt_count_differences_kernel(const uint32_t *p, const uint32_t *q, size_t words, unsigned long long *out) {
+    unsigned long long mine = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) mine += __popcll(__ballot(p[i] != q[i]));
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);     // (every lane of a wave holds the wave's count: lane 0 reports it)
 }
 
 // Known-answer probes of single device functions.

@@ -16,9 +16,13 @@
 //     with ONE cooperative 16-byte load per leaf, and the triangle loop then reads LDS broadcasts: the vector memory pipeline
 //     sees each record once per wave instead of once per lane and iteration, and a leaf step waits for global memory once for
 //     all of its triangles instead of once per triangle.
-// RPT_V_QUEUE adds the per-workgroup ray queue: see render_strip_queued below.
+// The per-workgroup ray queue is at the end of this file (render_strip_queued).
+// MEASURED AND NOT ADOPTED (round 3; profiles/r03_persistent_lds_ab.txt, r03_rayqueue_ab.txt): every form here is bit-identical
+// to the oracle and every form is slower than the kernel that is launched tile by tile — which is why this file is part of the
+// diagnostics library only.  DESIGN.md 6.3 has the numbers and the mechanism (one memory counter per wave, in issue order:
+// a persistent wave's next tile waits for its last tile's store and for its claim; a queue's barriers put four waves in lock step).
 #pragma once
-#include "rpt_kernels.hip.h"
+/* included by rpt_diag_kernels.hip.h (diagnostics build), after rpt_kernels.hip.h */
 
 #ifndef RPT_RELAXED_FP
 #pragma clang fp contract(off)
@@ -193,25 +197,6 @@ RPT_DEV void walk_uniform(const KernelArgs &a, int wave, int root, f3 origin, f3
             if (exit_is_past_hit(uv - origin, hit_dist, didHit)) alive = false;
         }
     }
-}
-
-// opencl_kernel.cl:287-306: normal, texture coordinates and the distance re-measured in the caller's frame
-RPT_DEV void mesh_hit_finish(const KernelArgs &a, const rpt_object &obj, f3 origin, f3 dir, int hitTri, f3 world_origin,
-                             float world_dirlen, Hit &hit) {
-    const float u = hit.uv.x, v = hit.uv.y;
-    const float w = 1.0f - u - v;
-    const f3 normA = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 0]]);
-    const f3 normB = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 1]]);
-    const f3 normC = ld3(a.normals[a.triangles[2 + 9 * hitTri + 3 * 2]]);
-    hit.normal = normalize(applyTranspose(obj.InvM, normA * w + normB * u + normC * v));
-    const rpt_float2 uvA = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 0]];
-    const rpt_float2 uvB = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 1]];
-    const rpt_float2 uvC = a.uvs[a.triangles[1 + 9 * hitTri + 3 * 2]];
-    hit.uv.x = w * uvA.x + u * uvB.x + v * uvC.x;
-    hit.uv.y = w * uvA.y + u * uvB.y + v * uvC.y;
-    const f3 objPoint = origin + dir * hit.dist;
-    const f3 worldPoint = transformPoint(obj.M, objPoint);
-    hit.dist = length(worldPoint - world_origin) / world_dirlen;
 }
 
 // sample_light (opencl_kernel.cl:488-545) for the lanes whose `need` is set, in uniform control flow.  The reference returns

@@ -24,8 +24,8 @@ class RenderError(RuntimeError):
 
 
 class Renderer:
-    def __init__(self, device: int = 0):
-        self._lib = _ffi.hip()
+    def __init__(self, device: int = 0, diag: bool = False):
+        self._lib = _ffi.hip_diag() if diag else _ffi.hip()      # diag: librpt_hip_diag.so (measurement arms; tools and tests only)
         h = C.c_void_p()
         rc = self._lib.rpt_create(C.byref(h), int(device))
         if rc != 0 or not h:
@@ -104,6 +104,12 @@ class Renderer:
 
     def set_variant(self, variant: int):
         self._check(self._lib.rpt_set_variant(self._h, int(variant)), "rpt_set_variant")
+
+    def verify_frame(self) -> int:
+        """Pixels whose packed colour differs between the kernel a frame would get and the un-culled kernel (0 = the culls changed nothing)."""
+        n = C.c_uint64(0)
+        self._check(self._lib.rpt_verify_frame(self._h, C.byref(n)), "rpt_verify_frame")
+        return int(n.value)
 
     def render(self):
         self._check(self._lib.rpt_render(self._h), "rpt_render")

@@ -21,9 +21,20 @@ def _built_libraries():
     cross-compiles without a GPU.  A box without the toolchain (none is planned) keeps what travelled with the snapshot."""
     import shutil
     if shutil.which("make"):
-        for d in (os.path.join(ROOT, "relativitypathtracer_amd", "csrc"), os.path.join(ROOT, "oracle")):
-            p = subprocess.run(["make", "-C", d, "all"], capture_output=True, text=True)
-            assert p.returncode == 0, f"make -C {d} failed:\n{p.stdout[-2000:]}\n{p.stderr[-2000:]}"
+        csrc = os.path.join(ROOT, "relativitypathtracer_amd", "csrc")
+        pkg = os.path.join(ROOT, "relativitypathtracer_amd")
+        have_hipcc = shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")
+        if have_hipcc:
+            # `diag`: librpt_hip_diag.so (the measurement arms tests/test_gpu_diag_arms.py checks against the oracle)
+            p = subprocess.run(["make", "-C", csrc, "all", "diag"], capture_output=True, text=True)
+            assert p.returncode == 0, f"make -C {csrc} failed:\n{p.stdout[-2000:]}\n{p.stderr[-2000:]}"
+        else:
+            # a box with make but no hipcc: keep the HIP library that travelled with the snapshot, build the host library only
+            assert os.path.exists(os.path.join(pkg, "librpt_hip.so")), "no hipcc and no prebuilt librpt_hip.so"
+            p = subprocess.run(["make", "-C", csrc, os.path.join("..", "librpt_scene.so")], capture_output=True, text=True)
+            assert p.returncode == 0, f"make librpt_scene.so failed:\n{p.stdout[-2000:]}\n{p.stderr[-2000:]}"
+        p = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "all"], capture_output=True, text=True)
+        assert p.returncode == 0, f"make -C oracle failed:\n{p.stdout[-2000:]}\n{p.stderr[-2000:]}"
     yield
 
 
