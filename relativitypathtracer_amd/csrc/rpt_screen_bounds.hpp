@@ -602,9 +602,62 @@ inline Rect box_rect(const rpt_object &o, int interval, const double bmin[3], co
                 r[axis] = lo[axis] + (hi[axis] - lo[axis]) * t;
                 return sub(D3{r[0], r[1], r[2]}, oc);
             };
-            // straight edges stay straight under a linear map: its two corners are the edge; under aberration an edge becomes a
-            // conic arc, followed adaptively from its two corners
-            curve.sample(acc, at, 1, !m.linear, &cu[k_lo], &cnd[k_lo], &cu[k_hi], &cnd[k_hi], rel_margin, extent, forced_tol);
+            // straight edges stay straight under a linear map: its two corners are the edge — WHEN BOTH ARE IN FRONT of the clip
+            // cone (the cone is convex).  If one or both are not, the stretch between them can still pass in front: the camera
+            // direction runs linearly from corner to corner, and close to the camera its length shrinks faster than its z — a wall
+            // a hundred units wide seen from a third of a unit away has all eight corners at the horizon, left and right, and fills
+            // the screen in between (found by tools/verify_sweep.py, round 3: ladder_paradox.txt's back wall, 74 % of the frame
+            // lost at one camera state in 16 000).  So such an edge is CUT with the cone exactly: nd(t) = A + t (B - A),
+            // nd.z > EPS |nd| is a quadratic inequality in t, and the part of the edge in front is the segment between its roots.
+            if (m.linear) {
+                const D3 A = cnd[k_lo], B = cnd[k_hi];
+                bool fa = false, fb2 = false;
+                acc.classify(A, fa);
+                acc.classify(B, fb2);
+                acc.pen_up();
+                if (fa && fb2) {
+                    acc.point(A);
+                    acc.point(B);
+                } else {
+                    clipped = true;
+                    const D3 Dv = sub(B, A);
+                    const double e2 = EPS_FRONT * EPS_FRONT;
+                    const double qa = Dv.z * Dv.z - e2 * dot(Dv, Dv), qb = 2.0 * (A.z * Dv.z - e2 * dot(A, Dv)), qc = A.z * A.z - e2 * dot(A, A);
+                    double cuts[4] = {0.0, 1.0, 0.0, 0.0};
+                    int n_cuts = 2;
+                    if (qa != 0.0) {
+                        const double disc = qb * qb - 4.0 * qa * qc;
+                        if (disc >= 0.0) {
+                            const double sq = std::sqrt(disc), q = -0.5 * (qb + (qb >= 0.0 ? sq : -sq));
+                            const double r1 = q / qa, r2 = q != 0.0 ? qc / q : r1;
+                            if (r1 > 0.0 && r1 < 1.0) cuts[n_cuts++] = r1;
+                            if (r2 > 0.0 && r2 < 1.0) cuts[n_cuts++] = r2;
+                        }
+                    } else if (qb != 0.0) {
+                        const double r1 = -qc / qb;
+                        if (r1 > 0.0 && r1 < 1.0) cuts[n_cuts++] = r1;
+                    }
+                    std::sort(cuts, cuts + n_cuts);
+                    auto nd_at = [&](double t) { return add(A, mul(Dv, t)); };
+                    double t_in0 = 2.0, t_in1 = -1.0;                    // the union of the pieces whose midpoint is in front (one piece: the cone is convex)
+                    for (int c2 = 0; c2 + 1 < n_cuts; c2++) {
+                        if (!(cuts[c2 + 1] > cuts[c2])) continue;
+                        if (Accum::is_front(nd_at(0.5 * (cuts[c2] + cuts[c2 + 1])))) { t_in0 = std::min(t_in0, cuts[c2]); t_in1 = std::max(t_in1, cuts[c2 + 1]); }
+                    }
+                    if (t_in1 > t_in0) {
+                        // (end points ON the cone have nd.z = EPS |nd| > 0: on the plane they lie on the horizon circle, where horizon() takes over)
+                        const D3 P0 = nd_at(t_in0), P1 = nd_at(t_in1);
+                        if (!(P0.z > 0.0) || !(P1.z > 0.0) || !finite3(P0) || !finite3(P1)) { acc.failed = true; break; }
+                        acc.point(P0);
+                        acc.point(P1);
+                        acc.n_crossings += (t_in0 > 0.0) + (t_in1 < 1.0);
+                    }
+                }
+                acc.pen_up();
+                continue;
+            }
+            // under aberration an edge becomes a conic arc, followed adaptively from its two corners
+            curve.sample(acc, at, 1, true, &cu[k_lo], &cnd[k_lo], &cu[k_hi], &cnd[k_hi], rel_margin, extent, forced_tol);
             tol_used = std::max(tol_used, curve.tol);
             clipped = clipped || curve.clipped;
             curve.draw(acc, false);                             // every edge is a polyline of its own

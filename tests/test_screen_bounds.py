@@ -201,6 +201,36 @@ def test_rectangles_contain_every_hit_cases_the_soak_runs_found(kind, seed):
         test_rectangles_contain_every_hit_random_scenes(seed)
 
 
+def _sweep_state(name, k, states=1000):
+    """State k of tools/verify_sweep.py's camera path (rest -> 0.99c along a turning direction, clock 0 -> 30 s)."""
+    import math
+    s = Scene.from_file(name)
+    f = k / (states - 1)
+    speed = 0.99 * f
+    ang, el = 2.0 * math.pi * 3.0 * f, 0.6 * math.sin(2.0 * math.pi * 5.0 * f)
+    s.set_camera((speed * math.cos(el) * math.sin(ang), speed * math.sin(el), speed * math.cos(el) * math.cos(ang)), 30.0 * f)
+    s.update_objects()
+    return s
+
+
+def test_rectangles_contain_every_hit_wall_with_every_corner_at_the_horizon():
+    """Found by tools/verify_sweep.py (rpt_verify_frame over 16 000 animated states, round 3): ladder_paradox.txt, state 311.  The
+    back wall (a cube scaled 100 x 2 x 0.01) seen from 0.29 units in front of it, light propagation off (the linear map): all eight
+    corners map to the horizon, left and right, NONE in front of the clip cone, and the wall fills 74 % of the frame in between.  A
+    straight edge between two such corners was taken to be invisible (its two corners were 'the edge'); the stretch in front is
+    now cut out of it exactly.  Neighbouring states and a synthetic wall of the same kind ride along."""
+    for k in (305, 309, 310, 311, 312, 313, 320):
+        check_scene(_sweep_state("ladder_paradox", k), 320, 180, f"ladder_paradox sweep state {k}")
+    for text in ("Oc\n p2,-2.5,3,0,0,1,0,100,2,0.01\n c1,1,1\nA0.5\nI\nR\n", "Oc\n p0,0,2,0.3,0,1,0,500,500,0.01\n c1,1,1\nA0.5\nI\nR\n",
+                 "Oc\n p0,-1,0,0,0,1,0,300,0.01,300\n c1,1,1\nA0.5\nI\nR\n"):
+        for v, t in (((0.0, 0.0, 0.0), 0.0), ((-0.12, -0.06, 0.28), 9.3), ((0.3, 0.0, 0.1), 2.0), ((0.0, 0.0, 0.9), 2.7)):
+            scene = Scene()
+            scene.inputScene(text)
+            scene.set_camera(v, t)
+            scene.update_objects()
+            check_scene(scene, 320, 180, f"wall {text[:30]!r} v={v} t={t}")
+
+
 ADVERSARIAL = [
     # huge and tiny scales, a slab seen edge-on, a box the camera stands on, one it is inside of, a sphere it touches
     "Oc\n p0,0,8,0,0,1,0,1000,1000,0.001\n c1,1,1\nOs\n p0.5,0.2,3,0,0,1,0,0.0001,0.0001,0.0001\n c1,1,1\nA0.5\nR\n",

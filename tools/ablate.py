@@ -29,8 +29,9 @@ def main():
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--only", default="")
+    ap.add_argument("--diag", action="store_true", help="librpt_hip_diag.so: the measurement arms (variants other than 0, 1, 3, 41, 43, 44, 50, 51)")
     args = ap.parse_args()
-    r = Renderer(0)
+    r = Renderer(0, diag=args.diag)
     r.set_variant(args.variant)
     res = {}
     for name, text in SCENES.items():

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--frames", type=int, default=40)
     ap.add_argument("--inflight", type=int, default=3)
     ap.add_argument("--only", default="")
+    ap.add_argument("--diag", action="store_true", help="librpt_hip_diag.so: the measurement arms (variants other than 0, 1, 3, 41, 43, 44, 50, 51)")
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(",")]
     rows = []
@@ -33,7 +34,7 @@ def main():
         s = Scene.from_file(name)
         s.set_camera(vel, t)
         s.update_objects()
-        slots = [Renderer(0) for _ in range(args.inflight)]
+        slots = [Renderer(0, diag=args.diag) for _ in range(args.inflight)]
         slots[0].upload_scene(s)
         for r in slots[1:]:
             r.share_scene(slots[0])

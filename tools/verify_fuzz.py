@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""rpt_verify_frame over the three scene generators of tests/scene_fuzz.py (random, extreme, close): every seed's scene at a
+random camera state, the culled kernels (41, 43) against the un-culled kernel (3) on the device.  No oracle render, so thousands
+of scenes per minute; the oracle comparison of the same generators is tests/test_gpu_fuzz.py.
+usage: python tools/verify_fuzz.py --first 0 --last 5000 [--kinds random,extreme,close]"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np                                              # noqa: E402
+import scene_fuzz                                               # noqa: E402
+from relativitypathtracer_amd import Scene                      # noqa: E402
+from relativitypathtracer_amd.renderer import Renderer          # noqa: E402
+
+
+def build(kind, seed):
+    if kind == "random":
+        rng = np.random.default_rng(1000 + seed)
+        text, _ = scene_fuzz.random_scene_text(rng)
+        speeds = [0.0, 0.0, 0.5, 0.95]
+        t = None
+    elif kind == "extreme":
+        rng = np.random.default_rng(550000 + seed)
+        text = scene_fuzz.extreme_scene_text(rng)
+        speeds = [0.0, 0.5, 0.9, 0.99, 0.999]
+        t = (-5, 40)
+    else:
+        rng = np.random.default_rng(880000 + seed)
+        text = scene_fuzz.close_scene_text(rng)
+        speeds = [0.0, 0.3, 0.9, 0.99]
+        t = (-3, 20)
+    if isinstance(text, tuple):
+        text = text[0]
+    s = Scene()
+    s.inputScene(text)
+    v = rng.normal(size=3)
+    v = v / np.linalg.norm(v) * rng.choice(speeds)
+    s.set_camera(tuple(float(c) for c in v), float(rng.uniform(*(t or (-3, 20)))))
+    s.update_objects()
+    return s, text
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--first", type=int, default=0)
+    ap.add_argument("--last", type=int, default=2000)
+    ap.add_argument("--kinds", default="random,extreme,close")
+    args = ap.parse_args()
+    r = Renderer(0)
+    sizes = [(320, 184), (256, 144), (200, 150), (640, 360)]
+    bad_total = 0
+    for kind in args.kinds.split(","):
+        bad, t0, done = 0, time.perf_counter(), 0
+        for seed in range(args.first, args.last):
+            try:
+                s, text = build(kind, seed)
+            except Exception as e:      # a generator may produce a scene the front end rejects
+                continue
+            W, H = sizes[seed % len(sizes)]
+            r.upload_scene(s)
+            r.set_scene_params(s, W, H)
+            r.set_output(None)
+            for variant in (0, 43):
+                r.set_variant(variant)
+                n = r.verify_frame()
+                if n:
+                    bad += 1
+                    print(f"  {kind} seed {seed} {W}x{H} variant {variant or 41}: {n} pixels differ", flush=True)
+            done += 1
+            if done % 1000 == 0:
+                print(f"  ... {kind}: {done} scenes, {bad} with differences, {time.perf_counter() - t0:.0f} s", flush=True)
+        bad_total += bad
+        print(f"{kind:8s} seeds {args.first}..{args.last - 1}: {done} scenes x 2 kernels, {bad} with differences, {time.perf_counter() - t0:.0f} s", flush=True)
+    r.close()
+    print(f"TOTAL: {bad_total} verifications with differences")
+    return 1 if bad_total else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
