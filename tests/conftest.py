@@ -73,6 +73,10 @@ REFERENCE_SHOTS = {
     # of 4.5555 s; the grab cannot tell the two apart — were found by fit_reference_camera.py::fit_moving_sphere): 336 of
     # 3.5 M pixels beyond 1 LSB.  Pins the boost of a textured sphere, its retarded position and the Terrell-rotated pattern.
     "sphere_moving": dict(text="TTextures/soccer.jpg\nOs\n p0,0,5,2,0,1,0,2,2,2\n t0\n v0.99,0,0\nR\n", v=(0.0, 0.0, 0.0), t=4.5555, interval=-1),
+    # Scenes/bunny.txt, the headline scene, "Stationary frame" (README.md:85-87): everything at rest, nothing to recover.  The
+    # grab shows the missing Models/StanfordBunny.obj; what it pins is the light sphere, the background and the framing
+    # (tests/golden/make_reference_fixtures.py), and the stand-in mesh's pose up to a similarity of the image plane.
+    "mesh1": dict(scene="bunny", v=(0.0, 0.0, 0.0), t=0.0, interval=-1),
     "shadows1": dict(scene="shadows", v=(0.0, 0.0, 0.0), t=6.157, interval=-1),
     "shadows2": dict(scene="shadows", v=(0.0, 0.0, 0.0), t=9.212, interval=-1),
     "shadows4": dict(scene="shadows", v=(0.0, 0.0, 0.0), t=18.229, interval=-1),
@@ -89,6 +93,64 @@ REFERENCE_GIF_FRAMES = {
 }
 LADDER_FRAME_CAMERA_V = (math.tanh(7361 / 5000.0), 0.0, 0.0)
 CLIENT_W, CLIENT_H = 2560, 1377      # client area of the reference's 2560x1400 window grabs
+
+
+MESH1_LIGHT_CROP = (300, 390, 1230, 1330)   # y0, y1, x0, x1 of tests/golden/ref_mesh1_crop_y300_x1230.png (the light sphere)
+MESH1_BUNNY_ROWS = 500                      # client rows below this hold the bunny (and nothing else but background)
+
+
+def silhouette_iou_under_similarity(ref_mask, our_mask, scales):
+    """Best intersection-over-union of two boolean masks when `our_mask` may be scaled (about the origin, nearest neighbour) by
+    one of `scales` and shifted: centroids aligned, then +-6 pixels in steps of 2.  Returns (iou, scale, dy, dx)."""
+    import numpy as np
+    hh, ww = ref_mask.shape
+    ya, xa = np.nonzero(ref_mask)
+    best = (0.0, None, 0, 0)
+    for sc in scales:
+        nh, nw = int(our_mask.shape[0] * sc), int(our_mask.shape[1] * sc)
+        yi = np.minimum((np.arange(nh) / sc).astype(int), our_mask.shape[0] - 1)
+        xi = np.minimum((np.arange(nw) / sc).astype(int), our_mask.shape[1] - 1)
+        nb = our_mask[yi][:, xi]
+        ys, xs = np.nonzero(nb)
+        if not len(ys):
+            continue
+        cy, cx = int(round(ya.mean() - ys.mean())), int(round(xa.mean() - xs.mean()))
+        for dy in range(cy - 6, cy + 7, 2):
+            for dx in range(cx - 6, cx + 7, 2):
+                c = np.zeros_like(ref_mask)
+                y0, x0, y1, x1 = max(0, dy), max(0, dx), min(hh, dy + nh), min(ww, dx + nw)
+                if y1 <= y0 or x1 <= x0:
+                    continue
+                c[y0:y1, x0:x1] = nb[y0 - dy:y1 - dy, x0 - dx:x1 - dx]
+                iou = float((ref_mask & c).sum()) / float((ref_mask | c).sum())
+                if iou > best[0]:
+                    best = (iou, float(sc), dy, dx)
+    return best
+
+
+def check_mesh1(img, ref_stride4, ref_light_crop):
+    """Scenes/bunny.txt at rest against the reference's own grab of it (Screenshots/mesh1.png).  img: client area, top-down int16
+    RGB.  The light sphere, the background and the framing are pinned pixel for pixel; the bunny's pixels are NOT (the grab shows
+    Models/StanfordBunny.obj, absent from the reference tree; Models/bunny.obj is the same model under another normalisation), only
+    its pose, up to a similarity of the image plane."""
+    import numpy as np
+    y0, y1, x0, x1 = MESH1_LIGHT_CROP
+    assert np.abs(img[y0:y1, x0:x1] - ref_light_crop).max() == 0, "the light sphere of Scenes/bunny.txt differs from the reference's grab"
+    sub = img[::4, ::4]
+    top = MESH1_BUNNY_ROWS // 4
+    assert np.abs(sub[:top] - ref_stride4[:top]).max() == 0, "rows above the bunny (light sphere + background) differ"
+    bg = ref_stride4[1, 1]
+    ref_fg = np.abs(ref_stride4 - bg).sum(axis=2) > 12
+    our_fg = np.abs(sub - bg).sum(axis=2) > 12
+    ref_fg[:top] = False
+    our_fg[:top] = False
+    # outside both silhouettes: background, identical
+    both_bg = ~ref_fg & ~our_fg
+    assert np.abs(sub[both_bg] - ref_stride4[both_bg]).max() == 0
+    assert (ref_fg & our_fg).sum() > 0.9 * our_fg.sum()                 # the stand-in sits inside the grab's bunny (it is smaller)
+    iou, scale, dy, dx = silhouette_iou_under_similarity(ref_fg, our_fg, [1.22 + 0.02 * k for k in range(8)])
+    assert iou > 0.92, (iou, scale, dy, dx)                             # same model, same pose: 0.944 at scale 1.28
+    return iou, scale
 
 
 def load_reference_shot(name):

@@ -44,6 +44,15 @@ bar; the client area is 2560x1377.
                          pattern.  With `v0.99,0,0` and the ball 0.99 x 4.5555 units along its path, 336 of the grab's
                          3 525 120 pixels are more than 1 LSB off.
 
+  mesh1.png              Scenes/bunny.txt — THE HEADLINE SCENE — from a camera at rest (README.md:85-87).  The grab shows
+                         Models/StanfordBunny.obj, which the reference tree lacks (.MISSING_LARGE_BLOBS); the stand-in
+                         Models/bunny.obj is the same model in the same pose under ANOTHER NORMALISATION (its silhouette is 0.78 x
+                         the grab's and shifted), so the mesh pixels cannot be pinned.  What the grab does pin for this scene:
+                         the light sphere (an analytic object: its 1 009 pixels, every one of them, byte for byte), the
+                         background, the camera's framing and the `p`/`c`/`l`/`A` lines of the scene file; and, up to a
+                         similarity of the image plane, the bunny's pose (silhouette IoU 0.94 at scale 1.28).  The crop holds
+                         the light sphere.
+
 Written per image: an exact stride-4 subsample of the client area (every 4th pixel of every 4th row, no
 filtering) and one full-resolution crop of the part with the most detail.
 """
@@ -68,6 +77,7 @@ CROPS = {
     "shadows2": (540, 980, 1200, 1720),
     "shadows4": (540, 980, 1200, 1720),  # the pear lit from the right, its shadow on the wall, the light sphere
     "shadows5": (540, 980, 1200, 1720),
+    "mesh1": (300, 390, 1230, 1330),     # the light sphere of Scenes/bunny.txt
 }
 
 for name, crop in CROPS.items():

@@ -386,7 +386,7 @@ def test_frames_in_flight_share_one_scene():
         slots[k].close()
 
 
-@pytest.mark.parametrize("shot", ["arch1", "arch2", "cube1", "cube2", "cube3", "sphere_stationary", "sphere_moving", "shadows1", "shadows2", "shadows4", "shadows5"])
+@pytest.mark.parametrize("shot", ["arch1", "arch2", "cube1", "cube2", "cube3", "sphere_stationary", "sphere_moving", "shadows1", "shadows2", "shadows4", "shadows5", "mesh1"])
 def test_hip_frame_against_the_reference_screenshots(renderer, shot):
     """The HIP path at the camera states of the reference's own screenshots (tests/conftest.py::REFERENCE_SHOTS),
     2560x1377: identical to the oracle on every pixel, and compared DIRECTLY with the reference's window grab
@@ -404,6 +404,10 @@ def test_hip_frame_against_the_reference_screenshots(renderer, shot):
     assert np.array_equal(got, opx["rgba"].reshape(CLIENT_H, CLIENT_W, 4))
     img = got[::-1, :, :3].astype(np.int16)
     ref = np.asarray(Image.open(os.path.join(GOLDEN, f"ref_{shot}_stride4.png")).convert("RGB")).astype(np.int16)
+    if shot == "mesh1":                    # the headline scene: light sphere, background and framing pixel for pixel; the bunny's pose only
+        from conftest import check_mesh1
+        check_mesh1(img, ref, np.asarray(Image.open(os.path.join(GOLDEN, "ref_mesh1_crop_y300_x1230.png")).convert("RGB")).astype(np.int16))
+        return
     d = np.abs(img[::4, ::4] - ref).max(axis=2)
     if shot.startswith("arch"):
         assert (d > 1).sum() <= 4 and (d > 0).mean() < 0.02
@@ -509,6 +513,73 @@ def test_16k_frame_structure_and_sampled_rows(renderer):
         got = rgba[r0:r0 + 8].cpu().numpy().view(np.uint8).reshape(8, W, 4)
         assert np.array_equal(got, want), f"rows {r0}..{r0 + 8}"
     del fb
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("split", ["equal", "weighted"])
+def test_config5_bunny_8k_as_an_8_way_shard(renderer, split):
+    """BASELINE.json configs[4] as written — Scenes/bunny.txt at 7680x4320 sharded by 8-row tiles over EIGHT ranks with 3-byte
+    colour planes and ONE root reassembly into the 531 MB framebuffer — with the eight ranks run one after another on this GPU
+    (no 8-GPU node is available to the builder; what differs from the real thing is the wire, not a byte of what is sent or of
+    where it lands).  equal: tile k -> rank k mod 8, every rank a plane (rpt_set_rows / rpt_scatter_colour_plane3).  weighted:
+    per period of 4 + 7 tiles rank 0 renders four straight into the framebuffer, ranks 1..7 one each (rpt_set_tile_pattern /
+    rpt_scatter_helper_planes3).  The assembled frame must be the single-context frame byte for byte, and sampled row bands the
+    oracle's."""
+    import torch
+    scene = load_config("bunny")
+    W, H, world = 7680, 4320, 8
+    _setup(renderer, scene, W, H)
+    renderer.set_debug_rgb(False)
+    want = torch.zeros(W * H * 4, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    renderer.set_output(want.data_ptr())
+    renderer.render()
+    fb = torch.zeros(W * H * 4, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    tiles = rdist.tile_count(H)
+    if split == "equal":
+        words = rdist.plane_words(W, H, world)
+        planes4 = torch.zeros(words, dtype=torch.int32, device="cuda")
+        packed = torch.zeros((world, words * 3), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for rank in range(world):
+            renderer.set_rows(rank, world, True)
+            renderer.set_plane_output(planes4.data_ptr())
+            renderer.render()
+            assert renderer.local_tiles() == rdist.local_tile_count(H, rank, world)
+            renderer.pack_colour_plane3(planes4.data_ptr(), packed[rank].data_ptr(), words)
+        renderer.scatter_colour_plane3(packed.data_ptr(), fb.data_ptr(), W, H, world, words * 3)
+        wire_bytes = (world - 1) * words * 3
+    else:
+        root_run = 4
+        period = root_run + world - 1
+        helper_tiles = (tiles + period - 1) // period
+        words = helper_tiles * 8 * W
+        planes4 = torch.zeros(words, dtype=torch.int32, device="cuda")
+        packed = torch.zeros((world, words * 3), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        renderer.set_tile_pattern(0, period, root_run, False)
+        renderer.set_output(fb.data_ptr())
+        renderer.render()
+        for j in range(1, world):
+            renderer.set_tile_pattern(root_run + j - 1, period, 1, True)
+            renderer.set_plane_output(planes4.data_ptr())
+            renderer.render()
+            renderer.pack_colour_plane3(planes4.data_ptr(), packed[j].data_ptr(), words)
+        renderer.scatter_helper_planes3(packed.data_ptr(), fb.data_ptr(), W, H, world, root_run, words * 3)
+        wire_bytes = (world - 1) * words * 3
+    renderer.sync()
+    torch.cuda.synchronize()
+    assert bool(torch.equal(fb, want)), f"{split}: the assembled 8K frame differs from the single-context frame"
+    assert 60e6 < wire_bytes < 100e6          # 7 ranks x 3 B/px of their share: 87 MB (equal), 63 MB (weighted) for a 531 MB framebuffer
+    rgba = fb.view(H * W, 4)[:, 2].view(H, W)
+    for r0 in (0, 1200, H // 2, 3000, H - 8):
+        opx, _, _ = oracle_ffi.render(scene, W, H, rows=(r0, r0 + 8), want_rgb=False)
+        assert np.array_equal(rgba[r0:r0 + 8].cpu().numpy().view(np.uint8).reshape(8, W, 4), opx["rgba"].reshape(H, W, 4)[r0:r0 + 8]), f"rows {r0}.."
+    renderer.set_rows(0, 1, False)
+    renderer.set_plane_output(None)
+    renderer.set_output(None)
+    del fb, want, planes4, packed
     torch.cuda.empty_cache()
 
 
