@@ -212,7 +212,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("RPT_FRAMES_IN_FLIGHT", "3")),
                     help="frames in flight (contexts on concurrent streams); 1 = one frame at a time, as the reference's runKernel()")
-    ap.add_argument("--frames-per-exchange", type=int, default=int(os.environ.get("RPT_FRAMES_PER_EXCHANGE", "4")),
+    ap.add_argument("--frames-per-exchange", type=int, default=int(os.environ.get("RPT_FRAMES_PER_EXCHANGE", "1")),
                     help="N>1: frames whose planes travel in ONE gather (a collective costs as much host and launch time as a frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="after timing, compare rank 0's framebuffer with the oracle on a few row bands")
@@ -278,23 +278,36 @@ def main():
     # N > 1: how the frame is split.  auto = measure this node (one rank's frame time, the gather's cost
     # model) and let rank 0 choose between the weighted split, and rendering everything on rank 0 when the exchange
     # would only slow it down; equal = tile k -> rank k mod N; solo / an integer = force that arrangement.
+    # The per-frame exchange is ONE ncclGather enqueued through ctypes on the exchange stream (relativitypathtracer_amd/rccl.py);
+    # torch.distributed stays the rendezvous (the driver launches the ranks with torchrun) and carries the 128-byte unique id once.
+    # RPT_EXCHANGE=torch: torch.distributed.gather instead (what rounds 1-2 used; also what the gloo rehearsals use).
+    comm = None
+    if (n > 1 or force_dist) and td.get_backend() == "nccl" and os.environ.get("RPT_EXCHANGE", "native") == "native":
+        from relativitypathtracer_amd import rccl
+        comm = rccl.Communicator(rank, td.get_world_size(), rccl.torch_broadcast_id(rank, torch.device("cuda", local_rank)))
     split, split_info, root_run = os.environ.get("RPT_SPLIT", "auto"), None, None
+    split_timings = None
     if (n > 1 or force_dist) and pipeline and args.gather == "plane3" and split != "equal":
         if split == "auto":
-            # the cost model proposes a split; it, its neighbours and "rank 0 alone" are then tried for a few batches
-            # each and the fastest is kept (every rank sees the same max-over-ranks times, so all agree)
-            model_run, split_info = rdist.calibrate_split(renderers, scene, W, H, rank, n, frames_per_exchange=args.frames_per_exchange)
-            cands = sorted({0, model_run} | ({max(1, model_run // 2), min(16, model_run * 2)} if model_run else {4}))
-            root_run, tried = rdist.autotune_split(renderers, scene, W, H, rank, n, cands, frames_per_exchange=args.frames_per_exchange,
-                                                   force_gather=force_dist, rounds=6)
-            split_info = dict(split_info, model_choice=model_run, tried_ms_per_frame={str(c): round(v * 1e3, 4) for c, v in tried.items()})
+            # the cost model proposes a split; it, its neighbours, the EQUAL split and "rank 0 alone" are then tried for a few
+            # batches each and the fastest is kept (every rank sees the same max-over-ranks times, so all agree).  All of the
+            # timings go into the JSON line: when "rank 0 alone" wins (a 0.1 ms frame is shorter than its own gather), the line
+            # still says what the equal and the weighted split cost on this node.
+            model_run, split_info = rdist.calibrate_split(renderers, scene, W, H, rank, n, frames_per_exchange=args.frames_per_exchange, comm=comm)
+            cands = [None] + sorted({0, model_run} | ({max(1, model_run // 2), min(16, model_run * 2)} if model_run else {4}))
+            best, tried = rdist.autotune_split(renderers, scene, W, H, rank, n, cands, frames_per_exchange=args.frames_per_exchange,
+                                               force_gather=force_dist, rounds=6, comm=comm)
+            name = lambda c: "equal" if c is None else ("solo" if c == 0 else f"weighted_root_run_{c}")
+            split_timings = {name(c): round(v * 1e3, 4) for c, v in tried.items()}
+            split_info = dict(split_info, model_choice=model_run, tried_ms_per_frame=split_timings, chosen=name(best))
+            root_run = best
             if n == 1:
                 root_run = None              # one-rank rehearsal: the measurements ran, there is nothing to split
         else:
             root_run = 0 if split == "solo" else int(split)
     frame = rdist.FrameSharder(renderers, W, H, rank, n, force_gather=force_dist, pipeline=pipeline,
                                plane_bytes={"plane3": 3, "plane4": 4, "full16": 16}[args.gather], root_run=root_run,
-                               frames_per_exchange=args.frames_per_exchange)   # allocates outputs; N == 1 renders straight into the framebuffers
+                               frames_per_exchange=args.frames_per_exchange, comm=comm)   # allocates outputs; N == 1 renders straight into the framebuffers
 
     animate = os.environ.get("RPT_BENCH_ANIMATE") == "1"     # rehearsal only: every frame differs (camera clock runs)
     clock = [t]
@@ -458,7 +471,11 @@ def main():
             rf["frac_kernel_alone"] = None
             rf["note_regime"] = "N > 1: no kernel-alone measurement in this run; frac is the device-level figure"
         if n > 1 or force_dist:
-            out["comm"] = {"backend": td.get_backend(), "world_size": n, "ranks_in_group": td.get_world_size()}
+            out["comm"] = {"backend": td.get_backend(), "world_size": n, "ranks_in_group": td.get_world_size(),
+                           "exchange": "ncclGather through ctypes (relativitypathtracer_amd/rccl.py), one per " + (f"{frame.group} frames" if frame.group > 1 else "frame") if comm is not None
+                                       else "torch.distributed.gather",
+                           "split_timings_ms_per_frame": split_timings,
+                           "note": "every N > 1 figure before an 8-GPU node has run this line is a rehearsal on one GPU or a model: none is a measurement of xGMI"}
         if not args.no_cpu_baseline and n == 1:
             out["cpu_baseline"] = cpu_baseline(scene, W, H)
             # second column of SURVEY.md §8(d): primary + shadow rays, the shadow rays counted by the oracle
@@ -484,6 +501,9 @@ def main():
         print(json.dumps(out), flush=True)
     if n > 1 or force_dist:
         td.barrier()
+        if comm is not None:
+            torch.cuda.synchronize()
+            comm.destroy()
         td.destroy_process_group()
     for rr in renderers:
         rr.close()

@@ -127,7 +127,7 @@ def reassemble_planes(planes: np.ndarray, width: int, height: int, world: int) -
 
 
 def calibrate_split(renderers, objects, width: int, height: int, rank: int, world: int, device=None, frames: int = 30,
-                    frames_per_exchange: int = 1):
+                    frames_per_exchange: int = 1, comm=None):
     """Measure what choose_root_run needs and agree on the split: every rank renders the whole frame `frames` times
     with len(renderers) frames in flight (rank 0's time counts), all ranks time gathers of the smallest and the
     largest helper plane (a linear cost model of the exchange on THIS node's links), rank 0 picks the split and
@@ -162,6 +162,22 @@ def calibrate_split(renderers, objects, width: int, height: int, rank: int, worl
     def time_gather(nbytes, reps=8):
         send = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         recv = torch.zeros((world, nbytes), dtype=torch.uint8, device=dev) if rank == 0 else None
+        if comm is not None:            # the exchange the frames will use: ncclGather through ctypes on the current stream
+            from . import rccl
+            cur = torch.cuda.current_stream(dev).cuda_stream
+
+            def one():
+                comm.gather(send.data_ptr(), recv.data_ptr() if rank == 0 else 0, nbytes, rccl.NCCL_UINT8, 0, cur)
+            for _ in range(2):
+                one()
+            sync()
+            td.barrier()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                one()
+            sync()
+            return (time.perf_counter() - t1) / reps
         for _ in range(2):
             td.gather(send, list(recv.unbind(0)) if rank == 0 else None, dst=0)
         sync()
@@ -189,8 +205,8 @@ def calibrate_split(renderers, objects, width: int, height: int, rank: int, worl
 
 
 def autotune_split(renderers, objects, width: int, height: int, rank: int, world: int, candidates, device=None,
-                   frames_per_exchange: int = 4, force_gather: bool = False, rounds: int = 3):
-    """Run each candidate arrangement (values of FrameSharder's root_run: 0 = rank 0 alone, a power of two = weighted)
+                   frames_per_exchange: int = 1, force_gather: bool = False, rounds: int = 3, comm=None):
+    """Run each candidate arrangement (values of FrameSharder's root_run: None = the equal split, 0 = rank 0 alone, a power of two = weighted)
     for `rounds` batches of frames and keep the fastest.  A candidate's time is the MAX over ranks of the wall time
     per frame (one all_reduce), so every rank holds the same numbers and picks the same arrangement; ties go to the
     smaller root_run.  Collectives per candidate: what its frames need, one barrier, one all_reduce — the same on
@@ -207,7 +223,7 @@ def autotune_split(renderers, objects, width: int, height: int, rank: int, world
     results = {}
     for cand in candidates:
         sharder = FrameSharder(renderers, width, height, rank, world, force_gather=force_gather, device=device, root_run=cand,
-                               frames_per_exchange=frames_per_exchange)
+                               frames_per_exchange=frames_per_exchange, comm=comm)
         n = rounds * max(sharder.group, 1)
         for _ in range(max(sharder.group, 1)):
             sharder.render_and_gather(objects)
@@ -228,7 +244,7 @@ def autotune_split(renderers, objects, width: int, height: int, rank: int, world
         del sharder
         if dev.type == "cuda":
             torch.cuda.empty_cache()
-    best = min(results, key=lambda c: (results[c], c))
+    best = min(results, key=lambda c: (results[c], -1 if c is None else c))
     return best, results
 
 
@@ -239,7 +255,7 @@ class _Slot:
 
 class _Batch:
     """The frames of one exchange: send / receive buffers, the root's framebuffers, and the events that order them."""
-    __slots__ = ("send", "recv", "fbs", "ready", "work", "done", "count")
+    __slots__ = ("send", "recv", "fbs", "ready", "work", "done", "gathered", "count")
 
 
 class FrameSharder:
@@ -263,7 +279,7 @@ class FrameSharder:
 
     def __init__(self, renderers, width: int, height: int, rank: int, world: int, force_gather: bool = False,
                  pipeline: bool = True, device=None, plane_bytes: int = 3, root_run: Optional[int] = None,
-                 frames_per_exchange: int = 4):
+                 frames_per_exchange: int = 1, comm=None):
         """`device`: where the output tensors live; default the current GPU.  A CPU device (tests/test_dist_gloo.py:
         gloo, stand-in renderers) runs the same rotation and exchange without streams.
         `plane_bytes`: bytes per pixel on the wire — 3 (default: the alpha byte of a packed colour is the constant
@@ -277,7 +293,11 @@ class FrameSharder:
         needed cross no link, so the root takes the larger share (choose_root_run sizes it).  0 = rank 0 renders the
         whole frame and nothing is exchanged (the other ranks idle): the arrangement to fall back to when the
         exchange is slower than rendering.
-        `pipeline` False: one slot, one frame per exchange, every stage waited for."""
+        `pipeline` False: one slot, one frame per exchange, every stage waited for.
+        `comm`: an rccl.Communicator — the gather is then ONE ncclGather enqueued through ctypes on the exchange stream (a few
+        microseconds of host time; torch.distributed is only the rendezvous), and one frame per exchange is the default: no
+        display latency is traded for host time.  None: torch.distributed.gather (gloo tests, the CPU rehearsals)."""
+        self.comm = comm
         import torch
         if not isinstance(renderers, (list, tuple)):
             renderers = [renderers]
@@ -357,6 +377,7 @@ class FrameSharder:
                          for _ in range(self.group)] if rank == 0 else None
                 b.ready = [torch.cuda.Event() for _ in range(self.group)] if self.on_gpu else None
                 b.done = torch.cuda.Event() if self.on_gpu else None
+                b.gathered = torch.cuda.Event() if self.on_gpu else None
                 b.work, b.count = None, 0
                 self.batches.append(b)
             if self.on_gpu:
@@ -439,6 +460,27 @@ class FrameSharder:
         import torch.distributed as td
         n = batch.count
         batch.count = 0
+        if self.on_gpu and self.comm is not None:          # ONE ncclGather through ctypes: no torch object on the per-frame path
+            from . import rccl
+            for k in range(n):
+                self.xstream.wait_event(batch.ready[k])
+            self.comm.gather(batch.send.data_ptr(), batch.recv.data_ptr() if self.rank == 0 else 0, batch.send.numel(),
+                             rccl.NCCL_UINT8 if self.plane_bytes == 3 else rccl.NCCL_INT32, 0, self.xstream.cuda_stream)
+            batch.work = True
+            if self.rank != 0:
+                batch.done.record(self.xstream)
+                return
+            batch.gathered.record(self.xstream)
+            self.side.wait_event(batch.gathered)
+            if self.full16:                                 # (its reassembly is torch copies: they need torch's current stream)
+                with torch.cuda.stream(self.side):
+                    self._reassemble(batch, n)
+            else:
+                self._reassemble(batch, n)                  # the scatter kernels take their stream as an argument
+            batch.done.record(self.side)
+            if not self.pipeline:
+                self.side.synchronize()
+            return
         glist = list(batch.recv.unbind(0)) if self.rank == 0 else None
         if self.on_gpu:
             for k in range(n):
@@ -454,31 +496,32 @@ class FrameSharder:
         batch.work = work
         if self.rank != 0:
             return
-        side = self.side.cuda_stream if self.on_gpu else None
-
-        def reassemble():
-            for k in range(n):
-                src = batch.recv[:, k * self.plane_unit:(k + 1) * self.plane_unit]
-                # the k-th frame's planes lie (group * plane_unit) elements apart, one per rank
-                stride = batch.recv.shape[1] * batch.recv.element_size()
-                if self.full16:                # every rank's tiles back to their rows: N strided copies of whole pixels
-                    fb = batch.fbs[k].view(-1, self.tile_words)
-                    for j in range(self.world):
-                        fb[j::self.world].copy_(src[j].view(-1, self.tile_words)[:local_tile_count(self.H, j, self.world)], non_blocking=True)
-                    continue
-                if self.weighted:
-                    self.r.scatter_helper_planes3(src.data_ptr(), batch.fbs[k].data_ptr(), self.W, self.H, self.world, self.root_run,
-                                                  stride, stream=side)
-                elif self.plane_bytes == 3:
-                    self.r.scatter_colour_plane3(src.data_ptr(), batch.fbs[k].data_ptr(), self.W, self.H, self.world, stride, stream=side)
-                else:
-                    self.r.scatter_colour_plane(src.data_ptr(), batch.fbs[k].data_ptr(), self.W, self.H, self.world, stride // 4, stream=side)
         if self.on_gpu:
             with torch.cuda.stream(self.side):
                 work.wait()
-                reassemble()
+                self._reassemble(batch, n)
                 batch.done.record(self.side)
             if not self.pipeline:
                 self.side.synchronize()
         else:
-            reassemble()
+            self._reassemble(batch, n)
+
+    def _reassemble(self, batch, n):
+        """rank 0: the gathered planes of the batch's n frames -> their framebuffers (on the side stream when on the GPU)"""
+        side = self.side.cuda_stream if self.on_gpu else None
+        for k in range(n):
+            src = batch.recv[:, k * self.plane_unit:(k + 1) * self.plane_unit]
+            # the k-th frame's planes lie (group * plane_unit) elements apart, one per rank
+            stride = batch.recv.shape[1] * batch.recv.element_size()
+            if self.full16:                # every rank's tiles back to their rows: N strided copies of whole pixels
+                fb = batch.fbs[k].view(-1, self.tile_words)
+                for j in range(self.world):
+                    fb[j::self.world].copy_(src[j].view(-1, self.tile_words)[:local_tile_count(self.H, j, self.world)], non_blocking=True)
+                continue
+            if self.weighted:
+                self.r.scatter_helper_planes3(src.data_ptr(), batch.fbs[k].data_ptr(), self.W, self.H, self.world, self.root_run,
+                                              stride, stream=side)
+            elif self.plane_bytes == 3:
+                self.r.scatter_colour_plane3(src.data_ptr(), batch.fbs[k].data_ptr(), self.W, self.H, self.world, stride, stream=side)
+            else:
+                self.r.scatter_colour_plane(src.data_ptr(), batch.fbs[k].data_ptr(), self.W, self.H, self.world, stride // 4, stream=side)

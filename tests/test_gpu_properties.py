@@ -427,7 +427,7 @@ def test_hip_frame_against_the_reference_screenshots(renderer, shot):
         assert (d > 2).mean() < 5e-4
 
 
-@pytest.mark.parametrize("split", ["equal", "4", "auto", "full16"])
+@pytest.mark.parametrize("split", ["equal", "4", "auto", "full16", "equal-torch"])
 def test_bench_exchange_path_over_rccl_with_one_rank(tmp_path, split):
     """bench.py's N > 1 frame path — colour planes, ONE RCCL gather per frame, root reassembly, three frames in
     flight — run as a real torch.distributed job of one rank (RPT_FORCE_DIST), camera clock running so that every
@@ -441,7 +441,9 @@ def test_bench_exchange_path_over_rccl_with_one_rank(tmp_path, split):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = {**os.environ, "RPT_FORCE_DIST": "1", "RPT_BENCH_ANIMATE": "1", "RPT_SPLIT": "equal" if split == "full16" else split}   # "4": the weighted split's root path
+    exchange = "torch" if split.endswith("-torch") else "native"      # native: ONE ncclGather per frame through ctypes (rccl.py); torch: torch.distributed.gather
+    split = split.split("-")[0]
+    env = {**os.environ, "RPT_FORCE_DIST": "1", "RPT_BENCH_ANIMATE": "1", "RPT_SPLIT": "equal" if split == "full16" else split, "RPT_EXCHANGE": exchange}   # "4": the weighted split's root path
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "14", "--warmup", "2",
            "--workload", "shadows", "--width", "1280", "--height", "720", "--no-cpu-baseline", "--check"]
@@ -453,6 +455,7 @@ def test_bench_exchange_path_over_rccl_with_one_rank(tmp_path, split):
     out = json.loads(line)
     assert out["check"] == "framebuffer rows identical to the oracle", out["check"]
     assert out["config"]["frames_in_flight"] == 3 and out["n_gpus"] == 1
+    assert out["comm"]["exchange"].startswith("ncclGather through ctypes" if exchange == "native" else "torch.distributed.gather"), out["comm"]
     if split == "auto":      # calibrate_split ran its gathers, barrier and broadcast over RCCL
         cal = out["config"]["split_calibration"]
         assert cal["frame_ms_one_rank"] > 0 and cal["gather_base_ms"] >= 0
