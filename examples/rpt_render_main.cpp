@@ -94,7 +94,7 @@ int main(int argc, char **argv) {
                     (void)finished;
                 }
             }
-            if (!rc) rc = ring.submit(desc.objects, (int)desc.object_count);
+            if (!rc) rc = ring.enqueue(desc.objects, (int)desc.object_count);
         }
         if (!rc && ring.drain() == nullptr) rc = ring.status() ? ring.status() : 1;
         if (!rc && dump_path && !dumped.empty()) rc = rpt_write_ppm(dump_path, dumped.data(), width, height);

@@ -13,13 +13,13 @@
  *         ... Lorentz update of cpu_objects ...
  *         void *finished = ring.acquire();                         // the frame submitted N calls ago, complete (or nullptr)
  *         if (finished) drawGL(finished);                          // consume it BEFORE its slot is given the next frame
- *         ring.submit(&cpu_objects[0], (int)cpu_objects.size());   // returns at once; overwrites what acquire() returned
+ *         (void)ring.enqueue(&cpu_objects[0], (int)cpu_objects.size());   // returns at once; overwrites what acquire() returned
  *     }
  *     void *last = ring.drain();                                   // wait for everything; the newest frame
  *
- * acquire() and submit() are two calls on purpose: the framebuffer acquire() hands out belongs to the slot that the next
- * submit() renders into, so the host must be done with it (drawn, copied, or its own stream made to wait) before it
- * submits.  (An earlier revision returned the pointer FROM submit(), i.e. after the overwriting launch was enqueued.)
+ * acquire() and enqueue() are two calls on purpose: the framebuffer acquire() hands out belongs to the slot that the next
+ * enqueue() renders into, so the host must be done with it (drawn, copied, or its own stream made to wait) before it
+ * enqueues.  (An earlier revision returned the pointer FROM a call named submit(), i.e. after the overwriting launch was enqueued.)
  *
  * Every call returns/propagates the library's status through status(); a failed call leaves the ring usable.
  */
@@ -69,17 +69,20 @@ public:
         }
         return status_;
     }
-    /* Wait for the frame the NEXT submit() will overwrite — the oldest one in flight — and return its framebuffer
+    /* Wait for the frame the NEXT enqueue() will overwrite — the oldest one in flight — and return its framebuffer
      * (device pointer, 16 B/pixel), complete; nullptr while the ring is still filling or after an error.  The pointer
-     * is valid until the next submit(). */
+     * is valid until the next enqueue(). */
     void *acquire() {
         if (slots_.empty() || submitted_ < slots_.size()) return nullptr;
         if (!check(next_, rpt_sync(slots_[next_]))) return nullptr;
         return rpt_output_ptr(slots_[next_]);
     }
     /* Render.cpp:202-205 without the finish: refresh Object[] and enqueue the frame in the next slot; returns the
-     * status.  The slot's previous frame (what acquire() returned) is overwritten. */
-    int submit(const void *objects, int count) {
+     * STATUS (0 = RPT_OK).  The slot's previous frame (what acquire() returned) is overwritten.
+     * (Until round 2 a method called submit() returned the finished frame's pointer, or nullptr: `if (ring.submit(..)) present();`
+     * written against that header would compile against a status-returning submit() and mean the opposite.  So the name is new,
+     * and the old one is deleted: such a call site fails to compile instead of changing its meaning.) */
+    [[nodiscard]] int enqueue(const void *objects, int count) {
         if (slots_.empty()) return status_;
         const size_t k = next_;
         if (!check(k, rpt_set_objects(slots_[k], objects, count))) return status_;
@@ -88,6 +91,7 @@ public:
         submitted_++;
         return status_;
     }
+    void *submit(const void *objects, int count) = delete;      /* see enqueue() */
     /* Wait for every frame in flight; returns the framebuffer of the newest one (nullptr if none was submitted). */
     void *drain() {
         for (size_t k = 0; k < slots_.size(); k++)

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <functional>
 #include <memory>
 #include <string>
@@ -44,6 +45,7 @@ struct Geometry {
     DeviceBuffer vertices, normals, uvs, triangles, octrees, octreeTris, textures;
     DeviceBuffer dnodes, dtris, dlinks;       // derived layouts (rpt_kernels.hip.h)
     bool compact_ok = false;                  // derived octree layout usable (children consecutive)
+    unsigned long long generation = 0;        // unique per upload (the rectangle cache of a context names its geometry by this, not by address)
     std::vector<int> node_new_index;          // reference node index -> index in the derived, breadth-first numbering
     int top_count = 0;                        // derived nodes [0, top_count) are the forest's top levels (<= RPT_TOP_MAX)
     std::vector<float> host_node_bounds;      // min.xyz,max.xyz per octree node (culling spheres of mesh roots)
@@ -78,7 +80,7 @@ struct rpt_ctx {
     DeviceBuffer dobjs;
     std::vector<rptb::Rect> rects;                    // last frame's per-object rectangles (reused for unchanged objects)
     int rect_interval = 0x7fffffff;
-    const void *rect_geo = nullptr;
+    unsigned long long rect_geo_generation = ~0ull;   // Geometry::generation the cached rectangles were computed against
     DeviceBuffer owned_out, owned_plane, owned_rgb;
     void *pinned_objects = nullptr;                   // RPT_STAGING_SLOTS pinned slots of Object[] + DObj[]
     size_t pinned_capacity = 0;
@@ -363,7 +365,7 @@ void build_dobjs(const rpt_ctx *ctx, const rpt_object *objs, int count, rptd::DO
 // rectangle is a pure function of the object's 320 bytes, the interval and (meshes) the root bounds: an object whose
 // record is byte-identical to the previous frame's (a camera at rest, a paused scene) keeps its rectangle.
 void build_rects(rpt_ctx *ctx, const rpt_object *objs, int count, rptb::Rect *out) {
-    const bool comparable = ctx->rect_interval == ctx->interval && ctx->rect_geo == ctx->geo.get() &&
+    const bool comparable = ctx->rect_interval == ctx->interval && ctx->rect_geo_generation == ctx->geo->generation &&
                             ctx->rects.size() == (size_t)count && ctx->host_objects.size() == (size_t)count * sizeof(rpt_object);
     const rpt_object *prev = comparable ? (const rpt_object *)ctx->host_objects.data() : nullptr;
     ctx->rects.resize((size_t)count);
@@ -377,7 +379,7 @@ void build_rects(rpt_ctx *ctx, const rpt_object *objs, int count, rptb::Rect *ou
         out[i] = ctx->rects[i] = rptb::object_rect(o, ctx->interval, root);
     }
     ctx->rect_interval = ctx->interval;
-    ctx->rect_geo = ctx->geo.get();
+    ctx->rect_geo_generation = ctx->geo->generation;
 }
 
 int validate_objects(rpt_ctx *ctx, const rpt_object *objs, int count) {
@@ -710,6 +712,11 @@ int rpt_upload_scene(rpt_ctx *ctx, const rpt_scene_desc *s) {
     // a fresh Geometry: contexts sharing the previous one (rpt_share_scene) keep it until they let go
     ctx->geo = std::make_shared<Geometry>();
     ctx->geo->device = ctx->device;
+    {   // (an address can be reused by a later Geometry; a generation cannot)
+        static std::atomic<unsigned long long> next_generation{1};
+        ctx->geo->generation = next_generation.fetch_add(1);
+    }
+    ctx->rects.clear();
     if (int rc = upload(ctx, ctx->geo->vertices, s->vertices, s->vertex_count * sizeof(rpt_float3))) return rc;
     if (int rc = upload(ctx, ctx->geo->normals, s->normals, s->normal_count * sizeof(rpt_float3))) return rc;
     if (int rc = upload(ctx, ctx->geo->uvs, s->uvs, s->uv_count * sizeof(rpt_float2))) return rc;
@@ -1329,8 +1336,10 @@ extern "C" int rpt_build_octree(rpt_ctx *ctx, const rpt_float3 *vertices, size_t
         RPT_HIP(ctx, hipStreamSynchronize(ctx->stream));             // the only wait of the build
         lap("wait");
         if (hdr.overflow) {
-            if (attempt >= 3) return fail(ctx, RPT_ERR_NOMEM, "rpt_build_octree: triangle lists keep outgrowing their buffers");
-            cap *= 4;
+            // the level that overflowed said how many entries it wanted; deeper levels can want more still (at most 8x per level in
+            // theory, ~1.3x in practice), so that figure gets a quarter on top, and the build may be repeated up to six times
+            if (attempt >= 6) return fail(ctx, RPT_ERR_NOMEM, "rpt_build_octree: triangle lists keep outgrowing their buffers");
+            cap = std::max<size_t>(cap * 2, (size_t)hdr.needed + (size_t)hdr.needed / 4);
             continue;
         }
         // read the levels back: nodes and lists of every level that has nodes

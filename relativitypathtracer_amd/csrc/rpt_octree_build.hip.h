@@ -102,6 +102,7 @@ struct BuildHeader {          // what the kernels of one level tell the next (de
     unsigned int list_len[8]; // entries in each level's list buffer
     unsigned int n_children, n_chunks, flag_total;   // of the level being split (scratch, rewritten per level)
     unsigned int overflow;    // a list outgrew its buffer: the build is repeated with a larger one
+    unsigned int needed;      // ... that holds at least this many entries per level (what the level that overflowed asked for)
 };
 
 constexpr unsigned long long HASH_EMPTY = ~0ull;
@@ -279,12 +280,12 @@ __global__ __launch_bounds__(1024) void chunk_scan_kernel(const unsigned int *__
         unsigned int total;
         const unsigned int before = block_exclusive_scan(v, &total, smem);
         if (i < n) chunk_out[i] = (unsigned int)(base + before);      // base <= capacity is checked below before anything is written there
-        base += total;
-        if (base > (unsigned long long)list_capacity) break;             // uniform: base is the same in every thread
+        base += total;                                                   // (summed to the end even past the capacity: the host wants to know how much was asked for)
     }
     if (threadIdx.x == 0) {
         if (base > (unsigned long long)list_capacity) {
             hdr->overflow = 1u;
+            hdr->needed = base > 0xffffffffull ? 0xffffffffu : (unsigned int)base;
             base = 0;
         }
         if (level + 1 < 8) hdr->list_len[level + 1] = (unsigned int)base;

@@ -88,7 +88,7 @@ def test_example_host_frames_in_flight(tmp_path):
 def test_frame_ring_acquire_hands_out_the_frame_of_n_submits_ago(tmp_path):
     """rpt::FrameRing::acquire() returns the OLDEST frame in flight, complete and not yet overwritten: the example host
     copies frame 17 of 40 back right after acquire() (while two newer frames are in flight) and the pixels are the
-    oracle's frame 17 — not frame 20, which the same slot receives in the following submit()."""
+    oracle's frame 17 — not frame 20, which the same slot receives in the following enqueue()."""
     import oracle_ffi
     from relativitypathtracer_amd import Scene
     exe = build(tmp_path)

@@ -67,6 +67,29 @@ def test_random_scene(renderer, seed):
     _culls_change_nothing(renderer, f"seed {seed}\n{text}")
 
 
+def test_rotating_seeds_on_the_device(renderer):
+    """64 scenes per generator with seeds that change from day to day (RPT_SOAK_DAY overrides), checked on the device alone:
+    rpt_verify_frame, culled kernels against the un-culled one (tools/verify_fuzz.py is the same loop for soak runs)."""
+    import sys
+    import time
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import verify_fuzz
+    day = int(os.environ.get("RPT_SOAK_DAY", time.time() // 86400))
+    for kind in ("random", "extreme", "close"):
+        for k in range(64):
+            seed = 100000 + (day * 64 + k) % 400000
+            try:
+                scene, text = verify_fuzz.build(kind, seed)
+            except Exception:
+                continue
+            W, H = [(320, 184), (256, 144), (200, 150), (640, 360)][seed % 4]
+            renderer.upload_scene(scene)
+            renderer.set_scene_params(scene, W, H)
+            renderer.set_output(None)
+            renderer.set_debug_rgb(False)
+            _culls_change_nothing(renderer, f"{kind} seed {seed} (rotating)\n{text}")
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RPT_EXTREME_FIRST", "0")), int(os.environ.get("RPT_EXTREME_LAST", "32"))))
 def test_extreme_scene(renderer, seed):
     """scene_fuzz.extreme_scene_text: relative gammas of several hundred, cameras thousands of radii away in an object's own

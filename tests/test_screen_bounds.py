@@ -231,6 +231,32 @@ def test_rectangles_contain_every_hit_wall_with_every_corner_at_the_horizon():
             check_scene(scene, 320, 180, f"wall {text[:30]!r} v={v} t={t}")
 
 
+def test_rectangles_contain_every_hit_rotating_seeds():
+    """A slice of the conservativeness soak with seeds that CHANGE from day to day (RPT_SOAK_DAY overrides the day; the seed is in
+    the assertion message of a failure, so a find can be pinned as a case of its own): the fixed seeds above can only ever re-check
+    what they checked before, and a bound that is wrong somewhere else stays silent in production — an object simply vanishes
+    from a tile.  Eight random scenes, four close ones, four extreme ones per run."""
+    import os
+    import time
+    from scene_fuzz import extreme_scene_text
+    day = int(os.environ.get("RPT_SOAK_DAY", time.time() // 86400))
+    for k in range(8):
+        test_rectangles_contain_every_hit_random_scenes(100000 + (day * 8 + k) % 900000)
+    for k in range(4):
+        seed = 100000 + (day * 4 + k) % 900000
+        check_scene(close_scene(seed), 200, 80, f"close {seed} (rotating)")
+    for k in range(4):
+        seed = 100000 + (day * 4 + k) % 400000
+        rng = np.random.default_rng(550000 + seed)
+        scene = Scene()
+        scene.inputScene(extreme_scene_text(rng))
+        v = rng.normal(size=3)
+        v = v / np.linalg.norm(v) * rng.choice([0.0, 0.5, 0.9, 0.99, 0.999])
+        scene.set_camera(tuple(float(c) for c in v), float(rng.uniform(-5, 40)))
+        scene.update_objects()
+        check_scene(scene, 160, 90, f"extreme {seed} (rotating)")
+
+
 ADVERSARIAL = [
     # huge and tiny scales, a slab seen edge-on, a box the camera stands on, one it is inside of, a sphere it touches
     "Oc\n p0,0,8,0,0,1,0,1000,1000,0.001\n c1,1,1\nOs\n p0.5,0.2,3,0,0,1,0,0.0001,0.0001,0.0001\n c1,1,1\nA0.5\nR\n",
