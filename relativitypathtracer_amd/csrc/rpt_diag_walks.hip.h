@@ -359,6 +359,85 @@ RPT_DEV bool octree_walk_x(const KernelArgs &a, const rpt_object &obj, int root,
     return true;
 }
 
+// Experiment (variants 529 / 541): the six neighbour indices come with the node record (the whole 64-B line in one round trip)
+// and the one the ray leaves through is picked BEFORE the triangle loop (the exit face is known by then), so an empty leaf costs
+// one round trip instead of two and no neighbour index is ever loaded on its own.
+struct NodeRecN { v4f lo, hi; v4i q2, q3; };
+RPT_DEV NodeRecN load_node_rec_n(const KernelArgs &a, int i) {
+    const v4f *p = reinterpret_cast<const v4f *>(a.dnodes + i);
+    NodeRecN r;
+    r.lo = p[0];
+    r.hi = p[1];
+    r.q2 = reinterpret_cast<const v4i *>(p)[2];
+    r.q3 = reinterpret_cast<const v4i *>(p)[3];
+    return r;
+}
+template <bool PIPELINE>
+RPT_DEV bool octree_walk_nbrec(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin,
+                               float world_dirlen, Hit &hit) {
+    int curr = root;
+    NodeRecN rec = load_node_rec_n(a, curr);
+    f2 d;
+    int closeSide, farSide;
+    f3 nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z), nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
+    if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
+    f3 uv = newRay.origin + newRay.dir * d.x;
+    if (d.x < 0) {
+        uv = (newRay.origin - nmin) / (nmax - nmin);
+        if (__float_as_int(rec.lo.w) != -1) {
+            curr = descend_to_leaf(a, __float_as_int(rec.lo.w), uv);
+            rec = load_node_rec_n(a, curr);
+        }
+        nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
+        nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
+        if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
+        uv = newRay.origin + newRay.dir * d.x;
+    }
+    const ExitPlan plan = makeExitPlan(normalize(newRay.dir / (nmax - nmin)));
+    bool didHit = false;
+    int hitTri = 0;
+    for (int steps = 1; steps <= RPT_MAX_LEAF_STEPS; steps++) {
+        nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
+        nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
+        uv = (uv - nmin) / (nmax - nmin);
+        if (__float_as_int(rec.lo.w) != -1) {
+            curr = descend_to_leaf(a, __float_as_int(rec.lo.w), uv);
+            rec = load_node_rec_n(a, curr);
+            nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
+            nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
+        }
+        int i = __float_as_int(rec.hi.w);
+        const int trisEnd = i + rec.q2.x;
+        farSide = getOppositeBoxSide(plan, uv);
+        int next = rec.q2.y;
+        next = farSide == 1 ? rec.q2.z : next;
+        next = farSide == 2 ? rec.q2.w : next;
+        next = farSide == 3 ? rec.q3.x : next;
+        next = farSide == 4 ? rec.q3.y : next;
+        next = farSide == 5 ? rec.q3.z : next;
+        if (PIPELINE) {
+            if (i < trisEnd) {
+                TriRec cur = load_tri_rec(a, i);
+                for (; i < trisEnd; i++) {
+                    TriRec nxt = cur;
+                    if (i + 1 < trisEnd) nxt = load_tri_rec(a, i + 1);
+                    test_tri_rec(cur, newRay, hit, hitTri, didHit);
+                    cur = nxt;
+                }
+            }
+        } else {
+            for (; i < trisEnd; i++) test_tri_rec(load_tri_rec(a, i), newRay, hit, hitTri, didHit);
+        }
+        uv = nmin + uv * (nmax - nmin);
+        if (exit_is_past_hit(uv - newRay.origin, hit.dist, didHit) || next == -1) break;
+        curr = next;
+        rec = load_node_rec_n(a, curr);
+    }
+    if (!didHit) return false;
+    mesh_hit_finish(a, obj, newRay.origin, newRay.dir, hitTri, world_origin, world_dirlen, hit);
+    return true;
+}
+
 // per-wave timeline (V == 4): start / end of the wave on the 100 MHz wall clock + the loop accounting of rpt_diag_lds
 struct DiagWaveClock { unsigned long long t_start; };
 template <int V>
@@ -391,6 +470,7 @@ RPT_DEV void diag_wave_end(const KernelArgs &a, DiagWaveClock c) {
 template <int V> RPT_DEV constexpr bool diag_walk_selected() { return V == 2 || V == 4 || V == 5 || V == 10 || V == 120 || V == 121 || V == 122 || V == 123 || V >= 256; }
 template <int V>
 RPT_DEV bool diag_walk(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin, float world_dirlen, Hit &hit) {
+    if (V == 529 || V == 541) return octree_walk_nbrec<V == 541>(a, obj, root, newRay, world_origin, world_dirlen, hit);
     if (V >= 256) return octree_walk_x<((V == 785 ? 273 : V) & 247)>(a, obj, root, newRay, world_origin, world_dirlen, hit);
     return octree_core_diag<V>(a, obj, root, newRay, world_origin, world_dirlen, hit);
 }
