@@ -478,12 +478,16 @@ def test_bench_several_ranks_on_one_gpu_over_gloo(n, split, gather):
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-    assert out["n_gpus"] == n and out["comm"] == {"backend": "gloo", "world_size": n, "ranks_in_group": n}
+    c = out["comm"]
+    assert out["n_gpus"] == n and (c["backend"], c["world_size"], c["ranks_in_group"]) == ("gloo", n, n) and c["exchange"] == "torch.distributed.gather"
+    assert "none is a measurement of xGMI" in c["note"]
     assert out["check"] == "framebuffer rows identical to the oracle", out["check"]
     if split == "equal":
         assert "tile k -> rank k mod N" in out["config"]["sharding"]
-    elif split == "auto":
-        assert out["config"]["split_calibration"]["tried_ms_per_frame"]
+    elif split == "auto":      # the equal split, "rank 0 alone" and the weighted candidates were all timed, and the line says so
+        tried = out["config"]["split_calibration"]["tried_ms_per_frame"]
+        assert "equal" in tried and "solo" in tried and any(k.startswith("weighted_root_run_") for k in tried)
+        assert out["comm"]["split_timings_ms_per_frame"] == tried and out["config"]["split_calibration"]["chosen"] in tried
     else:
         assert out["config"]["sharding"].startswith("weighted")
 
