@@ -120,3 +120,71 @@ def close_scene_text(rng):
         lines.append("I")
     lines.append("R")
     return "\n".join(lines) + "\n"
+
+
+def walls_scene_text(rng):
+    """Huge thin slabs, walls and beams a fraction of a unit from the camera, at any orientation, some of them moving, with and
+    without light propagation: every corner at or behind the horizon while the object fills the screen (the case rpt_verify_frame's
+    first sweep found in ladder_paradox.txt)."""
+    lines = []
+    n = int(rng.integers(1, 4))
+    for _ in range(n):
+        big = float(10.0 ** rng.uniform(1.0, 3.0))
+        thin = float(10.0 ** rng.uniform(-3.0, -0.5))
+        shape = rng.choice(["wall", "floor", "beam", "slab"])
+        sc = {"wall": (big, big * float(rng.uniform(0.01, 1.0)), thin), "floor": (big, thin, big), "beam": (big, thin, thin * float(rng.uniform(1, 30))),
+              "slab": (big * float(rng.uniform(0.05, 1)), big, thin)}[shape]
+        d = float(10.0 ** rng.uniform(-1.5, 0.7))
+        direction = rng.normal(size=3)
+        direction /= np.linalg.norm(direction)
+        pos = direction * d + rng.normal(size=3) * 0.3 * float(rng.random() < 0.5)
+        axis = rng.normal(size=3)
+        ang = float(rng.uniform(0, 6.28)) if rng.random() < 0.6 else 0.0
+        lines.append("Oc")
+        lines.append(" p%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f" % (pos[0], pos[1], pos[2], ang, axis[0], axis[1], axis[2], sc[0], sc[1], sc[2]))
+        lines.append(" c%.3f,%.3f,%.3f" % tuple(rng.uniform(0.2, 1.0, size=3)))
+        if rng.random() < 0.3:
+            v = rng.normal(size=3)
+            v = v / np.linalg.norm(v) * float(rng.choice([0.3, 0.9, 0.99]))
+            lines.append(" v%.4f,%.4f,%.4f" % (v[0], v[1], v[2]))
+    if rng.random() < 0.5:
+        lines += ["Os", " l1", " p%.3f,%.3f,%.3f,0,0,1,0,0.2,0.2,0.2" % tuple(rng.normal(size=3) * 2), " c1,1,1"]
+    lines.append("A%.3f" % rng.uniform(0.1, 0.9))
+    if rng.random() < 0.5:
+        lines.append("I")
+    lines.append("R")
+    return "\n".join(lines) + "\n"
+
+
+def ellipsoids_scene_text(rng):
+    """Spheres scaled into needles, discs and planets (scale ratios up to 1e5), a fraction of their smallest radius to hundreds of
+    their largest away from the camera, rotated, some moving, some textured, with a light half of the time."""
+    lines = []
+    if rng.random() < 0.4:
+        lines.append("TTextures/soccer.jpg")
+    n = int(rng.integers(1, 4))
+    for _ in range(n):
+        base = float(10.0 ** rng.uniform(-2.0, 2.5))
+        sc = [base * float(10.0 ** rng.uniform(-2.5, 0.0)) if rng.random() < 0.6 else base for _ in range(3)]
+        direction = rng.normal(size=3)
+        direction /= np.linalg.norm(direction)
+        d = max(sc) * float(10.0 ** rng.uniform(-0.3, 1.5)) if rng.random() < 0.7 else min(sc) * float(rng.uniform(1.05, 4.0))
+        pos = direction * d
+        axis = rng.normal(size=3)
+        ang = float(rng.uniform(0, 6.28)) if rng.random() < 0.7 else 0.0
+        lines.append("Os")
+        lines.append(" p%.5f,%.5f,%.5f,%.4f,%.4f,%.4f,%.4f,%.5f,%.5f,%.5f" % (pos[0], pos[1], pos[2], ang, axis[0], axis[1], axis[2], sc[0], sc[1], sc[2]))
+        lines.append(" c%.3f,%.3f,%.3f" % tuple(rng.uniform(0.2, 1.0, size=3)))
+        if lines[0].startswith("T") and rng.random() < 0.5:
+            lines.append(" t0")
+        if rng.random() < 0.4:
+            v = rng.normal(size=3)
+            v = v / np.linalg.norm(v) * float(rng.choice([0.3, 0.9, 0.99, 0.999]))
+            lines.append(" v%.4f,%.4f,%.4f" % (v[0], v[1], v[2]))
+    if rng.random() < 0.5:
+        lines += ["Os", " l1", " p%.3f,%.3f,%.3f,0,0,1,0,0.2,0.2,0.2" % tuple(rng.normal(size=3) * 2), " c1,1,1"]
+    lines.append("A%.3f" % rng.uniform(0.1, 0.9))
+    if rng.random() < 0.4:
+        lines.append("I")
+    lines.append("R")
+    return "\n".join(lines) + "\n"

@@ -3,6 +3,7 @@ rpt_object_screen_rect) are CONSERVATIVE: every pixel whose primary ray hits an 
 object alone — lies inside the object's rectangle.  Host code only: runs without a GPU.  (That the kernel's use of
 them never changes a frame is what the GPU parity, fuzz and culling tests check.)"""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -231,6 +232,19 @@ def test_rectangles_contain_every_hit_wall_with_every_corner_at_the_horizon():
             check_scene(scene, 320, 180, f"wall {text[:30]!r} v={v} t={t}")
 
 
+@pytest.mark.parametrize("seed,W,H", [(1598, 333, 77), (7396, 180, 320), (9588, 180, 320), (17216, 320, 184), (26583, 320, 180)])
+def test_rectangles_contain_every_hit_beams_with_both_ends_behind_the_camera(seed, W, H):
+    """Found by tools/verify_fuzz.py --kinds walls (scene_fuzz.walls_scene_text: huge thin slabs, walls and beams a fraction of a unit
+    from the camera; 5 of 30 000 scenes lost pixels): an aberrated edge — camera or object moving — hundreds of box-widths long, both
+    ends far BEHIND the camera, its middle tenth or thousandth in front.  Sixteenths of the edge's length never landed on that
+    stretch; the base samples of an aberrated edge are now uniform in the ANGLE it subtends at the camera (box_rect)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import verify_fuzz
+    scene, text = verify_fuzz.build("walls", seed)
+    check_scene(scene, W, H, f"walls {seed}")
+
+
 def test_rectangles_contain_every_hit_rotating_seeds():
     """A slice of the conservativeness soak with seeds that CHANGE from day to day (RPT_SOAK_DAY overrides the day; the seed is in
     the assertion message of a failure, so a find can be pinned as a case of its own): the fixed seeds above can only ever re-check
@@ -245,6 +259,12 @@ def test_rectangles_contain_every_hit_rotating_seeds():
     for k in range(4):
         seed = 100000 + (day * 4 + k) % 900000
         check_scene(close_scene(seed), 200, 80, f"close {seed} (rotating)")
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import verify_fuzz
+    for k in range(8):
+        seed = 100000 + (day * 8 + k) % 900000
+        check_scene(verify_fuzz.build("walls", seed)[0], 200, 112, f"walls {seed} (rotating)")
     for k in range(4):
         seed = 100000 + (day * 4 + k) % 400000
         rng = np.random.default_rng(550000 + seed)

@@ -18,7 +18,17 @@ from relativitypathtracer_amd.renderer import Renderer          # noqa: E402
 
 
 def build(kind, seed):
-    if kind == "random":
+    if kind == "walls":
+        rng = np.random.default_rng(990000 + seed)
+        text = scene_fuzz.walls_scene_text(rng)
+        speeds = [0.0, 0.0, 0.3, 0.9, 0.99]
+        t = (-3, 20)
+    elif kind == "ellipsoids":
+        rng = np.random.default_rng(660000 + seed)
+        text = scene_fuzz.ellipsoids_scene_text(rng)
+        speeds = [0.0, 0.0, 0.3, 0.9, 0.99]
+        t = (-3, 20)
+    elif kind == "random":
         rng = np.random.default_rng(1000 + seed)
         text, _ = scene_fuzz.random_scene_text(rng)
         speeds = [0.0, 0.0, 0.5, 0.95]
@@ -28,7 +38,7 @@ def build(kind, seed):
         text = scene_fuzz.extreme_scene_text(rng)
         speeds = [0.0, 0.5, 0.9, 0.99, 0.999]
         t = (-5, 40)
-    else:
+    elif kind == "close":
         rng = np.random.default_rng(880000 + seed)
         text = scene_fuzz.close_scene_text(rng)
         speeds = [0.0, 0.3, 0.9, 0.99]
@@ -51,7 +61,7 @@ def main():
     ap.add_argument("--kinds", default="random,extreme,close")
     args = ap.parse_args()
     r = Renderer(0)
-    sizes = [(320, 184), (256, 144), (200, 150), (640, 360)]
+    sizes = [(320, 184), (256, 144), (200, 150), (640, 360), (360, 640), (1024, 256), (333, 77), (1280, 720)]     # landscape, portrait, 4 : 1, odd
     bad_total = 0
     for kind in args.kinds.split(","):
         bad, t0, done = 0, time.perf_counter(), 0
