@@ -188,3 +188,36 @@ def ellipsoids_scene_text(rng):
         lines.append("I")
     lines.append("R")
     return "\n".join(lines) + "\n"
+
+
+def meshwalls_scene_text(rng):
+    """One or two MESH objects (pear, cube.obj, triangle, bunny) scaled into slabs and needles next to the camera or around it, a
+    light, sometimes a floor: the root box through the box bounds, the shadow-segment cull for meshes, walks that start inside."""
+    meshes = [str(rng.choice(["Models/pear.obj", "Models/cube.obj", "Models/triangle.obj", "Models/bunny.obj"]))]
+    lines = ["M" + m for m in meshes]
+    n = int(rng.integers(1, 3))
+    for _ in range(n):
+        base = float(10.0 ** rng.uniform(-1.0, 2.5))
+        sc = [base * float(10.0 ** rng.uniform(-3.0, 0.0)) if rng.random() < 0.6 else base for _ in range(3)]
+        direction = rng.normal(size=3)
+        direction /= np.linalg.norm(direction)
+        d = float(10.0 ** rng.uniform(-1.5, 1.0))
+        pos = direction * d
+        axis = rng.normal(size=3)
+        ang = float(rng.uniform(0, 6.28)) if rng.random() < 0.7 else 0.0
+        lines.append("Om0")
+        lines.append(" p%.5f,%.5f,%.5f,%.4f,%.4f,%.4f,%.4f,%.5f,%.5f,%.5f" % (pos[0], pos[1], pos[2], ang, axis[0], axis[1], axis[2], sc[0], sc[1], sc[2]))
+        lines.append(" c%.3f,%.3f,%.3f" % tuple(rng.uniform(0.2, 1.0, size=3)))
+        if rng.random() < 0.3:
+            v = rng.normal(size=3)
+            v = v / np.linalg.norm(v) * float(rng.choice([0.3, 0.9, 0.99]))
+            lines.append(" v%.4f,%.4f,%.4f" % (v[0], v[1], v[2]))
+    if rng.random() < 0.7:
+        lines += ["Os", " l1", " p%.3f,%.3f,%.3f,0,0,1,0,0.2,0.2,0.2" % tuple(rng.normal(size=3) * 2), " c1,1,1"]
+    if rng.random() < 0.4:
+        lines += ["Oc", " p0,-2,0,0,0,1,0,50,0.1,50", " c0.5,0.5,0.5"]
+    lines.append("A%.3f" % rng.uniform(0.1, 0.9))
+    if rng.random() < 0.3:
+        lines.append("I")
+    lines.append("R")
+    return "\n".join(lines) + "\n"

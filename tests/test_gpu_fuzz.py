@@ -75,7 +75,7 @@ def test_rotating_seeds_on_the_device(renderer):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import verify_fuzz
     day = int(os.environ.get("RPT_SOAK_DAY", time.time() // 86400))
-    for kind in ("random", "extreme", "close", "walls"):
+    for kind in ("random", "extreme", "close", "walls", "ellipsoids", "meshwalls"):
         for k in range(64):
             seed = 100000 + (day * 64 + k) % 400000
             try:
@@ -191,12 +191,13 @@ def test_random_scenes_three_in_flight(round_):
             r.close()
 
 
-@pytest.mark.parametrize("kind", ["walls", "ellipsoids"])
+@pytest.mark.parametrize("kind", ["walls", "ellipsoids", "meshwalls"])
 @pytest.mark.parametrize("seed", list(range(12)) + [1598, 7396, 9588, 17216, 26583])
 def test_walls_and_ellipsoids_against_the_oracle(renderer, kind, seed):
     """The two generators round 3 added for rpt_verify_frame soaks (scene_fuzz.walls_scene_text: huge thin slabs a fraction of a
     unit from the camera — five of its seeds lost pixels to the screen bounds before the fix and ride along here;
-    ellipsoids_scene_text: spheres scaled into needles and discs, scale ratios up to 1e5), against the ORACLE: the device check
+    ellipsoids_scene_text: spheres scaled into needles and discs, scale ratios up to 1e5; meshwalls_scene_text: meshes scaled into slabs
+    next to or around the camera), against the ORACLE: the device check
     says culled == un-culled, this says both are the reference's picture.  NaN colours (degenerate scales) must agree too."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))

@@ -28,6 +28,11 @@ def build(kind, seed):
         text = scene_fuzz.ellipsoids_scene_text(rng)
         speeds = [0.0, 0.0, 0.3, 0.9, 0.99]
         t = (-3, 20)
+    elif kind == "meshwalls":
+        rng = np.random.default_rng(440000 + seed)
+        text = scene_fuzz.meshwalls_scene_text(rng)
+        speeds = [0.0, 0.0, 0.3, 0.9, 0.99]
+        t = (-3, 20)
     elif kind == "random":
         rng = np.random.default_rng(1000 + seed)
         text, _ = scene_fuzz.random_scene_text(rng)
