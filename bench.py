@@ -44,7 +44,10 @@ sys.path.insert(0, ROOT)
 
 # what variant 0 launches (csrc/rpt_api.hip): by whether the frame's Object[] holds a mesh
 DEFAULT_KERNEL = "rpt_render_kernel_ballot_w5 (rpt_render_async: in-wave cull, natural tile order)"
-DEFAULT_KERNEL_BLOCKING = "rpt_render_kernel_ballot_first_w5 (the blocking rpt_render: the same kernel with the mesh rows dispatched first and the pipelined walk)"
+DEFAULT_KERNEL_BLOCKING = "rpt_render_kernel_ballot_first_w5 (the blocking rpt_render: the same kernel with the mesh rows dispatched first and the latency form of the walk)"
+DEFAULT_KERNEL_SMALL = ("rpt_render_kernel_ballot_first_w5 (rpt_render_async on a context of at most RPT_LATENCY_KERNEL_MAX_PIXELS = 3 000 000 pixels: the latency kernel, "
+                        "as for the blocking call)")
+LATENCY_KERNEL_MAX_PIXELS = 3000000     # include/rpt.h
 DEFAULT_KERNEL_NO_MESH = "rpt_render_kernel_analytic_w8 (the default kernel without the octree walk compiled in: this workload's Object[] holds no mesh; 8 waves per SIMD)"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md): the contract roofline for this path
 
@@ -423,7 +426,8 @@ def main():
         # duration / overlap, and achieved = bytes per launch / that (= bytes of all launches / wall time).
         overlap = max(1.0, kernel_sum_ms / (elapsed * 1e3)) if frame.depth > 1 else 1.0
         has_mesh = bool((np.asarray(scene.objects()["type"]) == 2).any())
-        kernel_name = ((DEFAULT_KERNEL if has_mesh else DEFAULT_KERNEL_NO_MESH) if args.variant == 0
+        local_pixels = W * (H if (n == 1 and not force_dist) else min(frame.local_rows, H))
+        kernel_name = ((DEFAULT_KERNEL_NO_MESH if not has_mesh else DEFAULT_KERNEL_SMALL if local_pixels <= LATENCY_KERNEL_MAX_PIXELS else DEFAULT_KERNEL) if args.variant == 0
                        else f"kernel variant {args.variant} (rpt_set_variant, include/rpt.h)")
         achieved = alg / (kernel_ms / overlap * 1e-3) / 1e9
         out = {

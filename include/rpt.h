@@ -48,6 +48,9 @@ enum rpt_status {
 };
 
 #define RPT_TILE_ROWS 8     /* height of one pixel-row tile (the sharding unit of rpt_set_rows) */
+/* rpt_render_async on a context that renders at most this many pixels per frame launches the latency kernel (43) like the
+ * blocking call: so few walks do not fill the chip even with three frames in flight (measured crossover: 2560x1440). */
+#define RPT_LATENCY_KERNEL_MAX_PIXELS 3000000
 
 const char *rpt_version(void);
 
@@ -108,15 +111,17 @@ int rpt_set_debug_rgb(rpt_ctx *ctx, void *device_ptr_or_null_or_1);
 
 /* Kernel variant: 0 = default (fastest validated); the others select alternative implementations of the same path for
  * A/B measurement.  All produce identical results.
- *   0   default: 44 when the current Object[] holds no mesh; else 41 for rpt_render_async, 43 for the blocking rpt_render;
- *       1 when the octree's children are not stored consecutively
+ *   0   default: 44 when the current Object[] holds no mesh; else 43 for the blocking rpt_render and for contexts of at
+ *       most RPT_LATENCY_KERNEL_MAX_PIXELS, 41 for rpt_render_async above that; 1 when the octree's children are not stored
+ *       consecutively
  *   1   reads the reference's Octree/triangle layouts only (any valid octree; no culling)
  *   3   derived layouts, every object tested for every pixel, 5 waves per SIMD: the NO-CULL escape hatch, and the frame
  *       rpt_verify_frame compares the culled kernels with
  *   41  every wavefront builds its own object mask from per-object image-plane rectangles (computed on the host in
  *       rpt_set_objects) with one lane-parallel test + __ballot, 5 waves per SIMD: what rpt_render_async launches
- *   43  41 with the band of tile rows that holds the meshes dispatched first and triangle records asked for one iteration
- *       ahead (whole-frame contexts): what the blocking rpt_render launches
+ *   43  41 with the band of tile rows that holds the meshes dispatched first (whole-frame contexts) and the latency form of
+ *       the walk: triangle records asked for one iteration ahead, a leaf's first record together with its node record
+ *       (a second copy of it, addressable by node index): what the blocking rpt_render launches
  *   44  41 without the octree walk compiled in (61 VGPRs, no scratch, 8 waves per SIMD): what frames without a mesh object
  *       get; asked for explicitly while Object[] holds a mesh, 41 is launched instead
  *   50, 51      NOT bit-exact, opt-in only: 41 compiled with the arithmetic OpenCL C allows by default (fma contraction,

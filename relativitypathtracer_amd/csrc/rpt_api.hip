@@ -44,6 +44,7 @@ struct Geometry {
     int device = 0;
     DeviceBuffer vertices, normals, uvs, triangles, octrees, octreeTris, textures;
     DeviceBuffer dnodes, dtris, dlinks;       // derived layouts (rpt_kernels.hip.h)
+    DeviceBuffer dfirst;                      // first triangle record of every node's list, by node index (the latency walk)
     bool compact_ok = false;                  // derived octree layout usable (children consecutive)
     unsigned long long generation = 0;        // unique per upload (the rectangle cache of a context names its geometry by this, not by address)
     std::vector<int> node_new_index;          // reference node index -> index in the derived, breadth-first numbering
@@ -54,7 +55,7 @@ struct Geometry {
     size_t vertex_count = 0, normal_count = 0, uv_count = 0, triangle_words = 0, octree_count = 0, octree_tri_count = 0;
     ~Geometry() {
         (void)hipSetDevice(device);
-        for (DeviceBuffer *b : {&vertices, &normals, &uvs, &triangles, &octrees, &octreeTris, &textures, &dnodes, &dtris, &dlinks}) release(*b);
+        for (DeviceBuffer *b : {&vertices, &normals, &uvs, &triangles, &octrees, &octreeTris, &textures, &dnodes, &dtris, &dlinks, &dfirst}) release(*b);
     }
 };
 
@@ -304,6 +305,12 @@ int build_derived_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
     if (int rc = upload(ctx, g.dnodes, nodes.data(), nodes.size() * sizeof(rptd::DNode))) return rc;
     if (int rc = upload(ctx, g.dlinks, links.data(), links.size() * sizeof(int32_t))) return rc;
     if (int rc = upload(ctx, g.dtris, tris.data(), tris.size() * sizeof(rptd::DTri))) return rc;
+    {   // the first record of every list again, by node index (load_first_tri)
+        std::vector<rptd::DTri> first(n);
+        std::memset(first.data(), 0, first.size() * sizeof(rptd::DTri));
+        for (size_t k = 0; k < n; k++) if (nodes[k].leafCount > 0) first[k] = tris[(size_t)nodes[k].leafBegin];
+        if (int rc = upload(ctx, g.dfirst, first.data(), first.size() * sizeof(rptd::DTri))) return rc;
+    }
     g.compact_ok = true;
     return RPT_OK;
 }
@@ -513,7 +520,7 @@ int launch_diagnostic(rpt_ctx *ctx, rptd::KernelArgs &a, dim3 grid, int tiles, i
     }
     case 61: hipLaunchKernelGGL(rptd::rpt_render_kernel_queue_w5, grid, dim3(256), 0, ctx->stream, a); break;
     RPT_LAUNCH_X(256) RPT_LAUNCH_X(257) RPT_LAUNCH_X(259) RPT_LAUNCH_X(261) RPT_LAUNCH_X(263) RPT_LAUNCH_X(265) RPT_LAUNCH_X(269)
-    RPT_LAUNCH_X(273) RPT_LAUNCH_X(277) RPT_LAUNCH_X(285) RPT_LAUNCH_X(305) RPT_LAUNCH_X(317) RPT_LAUNCH_X(337) RPT_LAUNCH_X(349) RPT_LAUNCH_X(401) RPT_LAUNCH_X(785) RPT_LAUNCH_X(529) RPT_LAUNCH_X(541)
+    RPT_LAUNCH_X(273) RPT_LAUNCH_X(277) RPT_LAUNCH_X(285) RPT_LAUNCH_X(305) RPT_LAUNCH_X(317) RPT_LAUNCH_X(337) RPT_LAUNCH_X(349) RPT_LAUNCH_X(401) RPT_LAUNCH_X(785) RPT_LAUNCH_X(529) RPT_LAUNCH_X(541) RPT_LAUNCH_X(561) RPT_LAUNCH_X(573)
     case 1257: hipLaunchKernelGGL(rptd::rpt_render_kernel_x257_w6, grid, dim3(256), 0, ctx->stream, a); break;
     case 2257: hipLaunchKernelGGL(rptd::rpt_render_kernel_x257_w4, grid, dim3(256), 0, ctx->stream, a); break;
     case 2259: hipLaunchKernelGGL(rptd::rpt_render_kernel_x259_w4, grid, dim3(256), 0, ctx->stream, a); break;
@@ -547,6 +554,7 @@ int launch(rpt_ctx *ctx) {
     a.dnodes = (const rptd::DNode *)ctx->geo->dnodes.ptr;
     a.dtris = (const rptd::DTri *)ctx->geo->dtris.ptr;
     a.links = (const int *)ctx->geo->dlinks.ptr;
+    a.first_tris = (const rptd::DTri *)ctx->geo->dfirst.ptr;
     a.top_count = ctx->geo->top_count;
     a.dobjs = (const rptd::DObj *)((const char *)ctx->objects.ptr + (size_t)ctx->object_count * sizeof(rpt_object));
     a.objects = (const rpt_object *)ctx->objects.ptr;
@@ -597,7 +605,10 @@ int launch(rpt_ctx *ctx) {
     // frame is as long as its longest wave — so the band of tile rows that holds the meshes is dispatched first and the walk asks
     // for its triangle records an iteration ahead (43).  A frame whose Object[] holds no mesh gets the kernel without the octree
     // walk (44): 8 waves per SIMD instead of 5.  An octree the derived layout cannot hold gets the general kernel (1).
-    int v = ctx->variant == 0 ? (!ctx->has_mesh ? 44 : (ctx->latency_call ? 43 : 41)) : ctx->variant;
+    // Frames in flight that are too small to fill the chip with walks wait for latency as well (profiles/r03_latency_walk_ab.txt:
+    // 43 ahead of 41 up to 1920x1080 — bunny -6 %, shadows -19 % — level at 2560x1440, behind from 3200x1800): 43 for those too.
+    const bool small_frame = (size_t)tiles * RPT_TILE_ROWS * (size_t)ctx->width <= (size_t)RPT_LATENCY_KERNEL_MAX_PIXELS;
+    int v = ctx->variant == 0 ? (!ctx->has_mesh ? 44 : (ctx->latency_call || small_frame ? 43 : 41)) : ctx->variant;
     if (v == 44 && ctx->has_mesh) v = 41;          // (asked for explicitly on a scene with meshes: the full kernel)
     if (!ctx->geo->compact_ok && v != 44) v = 1;
     const bool band_first = v == 43

@@ -438,6 +438,8 @@ RPT_DEV bool octree_walk_nbrec(const KernelArgs &a, const rpt_object &obj, int r
     return true;
 }
 
+// Variants 561 / 573: the A/B arms of the product's latency walk (octree_walk<true, true>: a leaf's first triangle record is
+// addressable by the node's index and asked for with the node record) in natural order / mesh band first, against 273 / 285.
 // per-wave timeline (V == 4): start / end of the wave on the 100 MHz wall clock + the loop accounting of rpt_diag_lds
 struct DiagWaveClock { unsigned long long t_start; };
 template <int V>
@@ -470,6 +472,7 @@ RPT_DEV void diag_wave_end(const KernelArgs &a, DiagWaveClock c) {
 template <int V> RPT_DEV constexpr bool diag_walk_selected() { return V == 2 || V == 4 || V == 5 || V == 10 || V == 120 || V == 121 || V == 122 || V == 123 || V >= 256; }
 template <int V>
 RPT_DEV bool diag_walk(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin, float world_dirlen, Hit &hit) {
+    if (V == 561 || V == 573) return octree_walk<true, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);
     if (V == 529 || V == 541) return octree_walk_nbrec<V == 541>(a, obj, root, newRay, world_origin, world_dirlen, hit);
     if (V >= 256) return octree_walk_x<((V == 785 ? 273 : V) & 247)>(a, obj, root, newRay, world_origin, world_dirlen, hit);
     return octree_core_diag<V>(a, obj, root, newRay, world_origin, world_dirlen, hit);

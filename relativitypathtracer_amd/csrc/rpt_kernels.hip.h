@@ -100,7 +100,8 @@ struct KernelArgs {
     const DNode *dnodes;
     const DTri *dtris;
     const DObj *dobjs;
-    const int *links;               // DNode::link of every node again, 4 B apart: what a descent reads below the levels held in LDS
+    const int *links;               // DNode::link of every node again, 4 B apart: what a descent reads per level
+    const DTri *first_tris;         // per node: the first triangle record of its leaf list again, addressable by the NODE's index
     int top_count;                  // nodes [0, top_count) are the forest's top levels (whole levels, <= RPT_TOP_MAX)
     // persistent kernels (rpt_persistent.hip.h): the band of tile rows that holds the meshes (first_ty, first_h above) is
     // claimed tile by tile from per-queue counters, the other rows are dealt statically in runs of RPT_SKY_RUN tiles
@@ -413,6 +414,19 @@ RPT_DEV TriRec load_tri_rec(const KernelArgs &a, int k) {
     r.tri = __float_as_int(t2.y);
     return r;
 }
+// The first record of a node's list, by NODE index (48 B per node, zeros where the list is empty): its address is known as soon as
+// the node's is, so the latency walk asks for it together with the node record — one exposed round trip less per non-empty leaf,
+// 48 B more asked of the L1 per node visited.
+RPT_DEV TriRec load_first_tri(const KernelArgs &a, int node) {
+    const v4f *p = reinterpret_cast<const v4f *>(a.first_tris + node);
+    TriRec r;
+    r.t0 = p[0];
+    r.t1 = p[1];
+    const float2 t2 = *reinterpret_cast<const float2 *>(p + 2);
+    r.e2z = t2.x;
+    r.tri = __float_as_int(t2.y);
+    return r;
+}
 RPT_DEV void test_tri_rec(const TriRec &r, const Ray &ray, Hit &hit, int &hitTri, bool &didHit) {
     float dist;
     f2 triUV;
@@ -438,7 +452,8 @@ RPT_DEV int descend_to_leaf(const KernelArgs &a, int link, f3 &uv) {
     return idx;
 }
 
-template <bool PIPELINE>
+// PIPELINE: triangle records one iteration ahead.  FIRST (with PIPELINE): the first record of a leaf comes with its node record.
+template <bool PIPELINE, bool FIRST>
 RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin,
                          float world_dirlen, Hit &hit) {
     int curr = root;
@@ -462,6 +477,8 @@ RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, c
     const ExitPlan plan = makeExitPlan(normalize(newRay.dir / (nmax - nmin)));
     bool didHit = false;
     int hitTri = 0;
+    TriRec first;
+    if (FIRST) first = load_first_tri(a, curr);
     for (int steps = 1; steps <= RPT_MAX_LEAF_STEPS; steps++) {
         nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
         nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
@@ -469,6 +486,7 @@ RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, c
         if (__float_as_int(rec.lo.w) != -1) {
             curr = descend_to_leaf(a, __float_as_int(rec.lo.w), uv);
             rec = load_node_rec(a, curr);
+            if (FIRST) first = load_first_tri(a, curr);
             nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
             nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
         }
@@ -478,7 +496,7 @@ RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, c
         const int next = a.dnodes[curr].nb[farSide];
         if (PIPELINE) {
             if (i < trisEnd) {
-                TriRec cur = load_tri_rec(a, i);
+                TriRec cur = FIRST ? first : load_tri_rec(a, i);
                 for (; i < trisEnd; i++) {
                     TriRec nxt = cur;
                     if (i + 1 < trisEnd) nxt = load_tri_rec(a, i + 1);
@@ -493,6 +511,7 @@ RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, c
         if (exit_is_past_hit(uv - newRay.origin, hit.dist, didHit) || next == -1) break;
         curr = next;
         rec = load_node_rec(a, curr);
+        if (FIRST) first = load_first_tri(a, curr);
     }
     if (!didHit) return false;
     mesh_hit_finish(a, obj, newRay.origin, newRay.dir, hitTri, world_origin, world_dirlen, hit);
@@ -505,14 +524,15 @@ RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, c
 namespace rptd {
 #endif
 
-// Which walk a kernel variant uses.  V = 0: the reference's layouts; V = 23 (the blocking call's kernel): the pipelined form.
+// Which walk a kernel variant uses.  V = 0: the reference's layouts; V = 23 (kernel 43: the blocking call, and frames in flight
+// too small to fill the chip with walks): the latency form — records an iteration ahead, a leaf's first record with its node.
 template <int V>
 RPT_DEV bool mesh_walk(const KernelArgs &a, const rpt_object &obj, int i, const Ray &newRay, f3 world_origin, float world_dirlen, Hit &hit) {
 #ifdef RPT_DIAGNOSTICS
     if (diag_walk_selected<V>()) return diag_walk<V>(a, obj, a.dobjs[i].root, newRay, world_origin, world_dirlen, hit);
 #endif
     if (V == 0) return octree_core_ref(a, obj, newRay, world_origin, world_dirlen, hit);
-    return octree_walk<V == 23>(a, obj, a.dobjs[i].root, newRay, world_origin, world_dirlen, hit);
+    return octree_walk<V == 23, V == 23>(a, obj, a.dobjs[i].root, newRay, world_origin, world_dirlen, hit);
 }
 
 RPT_DEV float max3(f3 v) { return cl_max(cl_max(v.x, v.y), v.z); }   // opencl_kernel.cl:310
@@ -938,8 +958,8 @@ __global__ __launch_bounds__(256) void rpt_render_kernel_v0(const KernelArgs a) 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_unculled_w5(const KernelArgs a) { render_pixel_body<1>(a); }         // 3: no cull (rpt_verify_frame; the escape hatch)
 // the wave's object mask from the per-object screen rectangles by lane-parallel test + __ballot, 5 waves per SIMD (96 VGPRs, no scratch)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_w5(const KernelArgs a) { render_pixel_body<20>(a); }          // 41 = rpt_render_async
-// the same with the tile rows that hold the meshes dispatched first and the pipelined walk (40 B of scratch): latency, not throughput
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_first_w5(const KernelArgs a) { render_pixel_body<23>(a); }    // 43 = the blocking rpt_render
+// the same with the tile rows that hold the meshes dispatched first and the latency walk (40 B of scratch): latency, not throughput
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_first_w5(const KernelArgs a) { render_pixel_body<23>(a); }    // 43 = the blocking rpt_render; rpt_render_async below RPT_LATENCY_KERNEL_MAX_PIXELS
 // without the octree walk compiled in, for frames whose Object[] holds no mesh: 61 VGPRs, no scratch, EIGHT waves per SIMD
 // (arch 1080p 0.0370 -> 0.0301 ms per frame in flight, cubes.txt 4K 0.0898 -> 0.0725)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_analytic_w8(const KernelArgs a) { render_pixel_body<24>(a); }        // 44

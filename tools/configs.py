@@ -24,11 +24,19 @@ def main():
     ap.add_argument("--frames", type=int, default=40)
     ap.add_argument("--inflight", type=int, default=3)
     ap.add_argument("--only", default="")
+    ap.add_argument("--sizes", default="", help="WxH,WxH,...: render each selected scene (first entry of its name) at these sizes instead")
     ap.add_argument("--diag", action="store_true", help="librpt_hip_diag.so: the measurement arms (variants other than 0, 1, 3, 41, 43, 44, 50, 51)")
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(",")]
     rows = []
-    for name, W, H, vel, t in CONFIGS:
+    configs = CONFIGS
+    if args.sizes:
+        first = {}
+        for c in CONFIGS:
+            first.setdefault(c[0], c)
+        configs = [(n, int(wh.split("x")[0]), int(wh.split("x")[1]), first[n][3], first[n][4])
+                   for n in (args.only.split(",") if args.only else first) for wh in args.sizes.split(",")]
+    for name, W, H, vel, t in configs:
         if args.only and name not in args.only.split(","):
             continue
         s = Scene.from_file(name)
