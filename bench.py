@@ -10,7 +10,7 @@ does every frame, Render.cpp:202) + render every pixel; with N > 1 each rank ren
 and a root-side kernel expands them into the 16 B/pixel framebuffer.  Scene buffers are resident in
 HBM before the timed region; the framebuffer stays in device memory (the reference never reads back).
 
-Frames in flight (--inflight, default 3): a frame's critical path is the serial octree walk of its dearest pixel,
+Frames in flight (--inflight, default 4 = one slot per hardware queue of the process): a frame's critical path is the serial octree walk of its dearest pixel,
 which leaves most of the GPU idle for most of one frame; consecutive frames are therefore submitted on separate
 streams (one context per slot) and overlap on the device.  Every frame is still refreshed, rendered completely
 and kept in its slot's framebuffer; `value` is frames/second x pixels over the K timed steps.  The same frames
@@ -213,8 +213,9 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("RPT_FRAMES_IN_FLIGHT", "3")),
-                    help="frames in flight (contexts on concurrent streams); 1 = one frame at a time, as the reference's runKernel()")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("RPT_FRAMES_IN_FLIGHT", "4")),
+                    help="frames in flight (contexts on concurrent streams; default 4 = one per hardware queue of a HIP process — a fifth shares a queue "
+                         "and loses, profiles/r03_frames_in_flight.txt); 1 = one frame at a time, as the reference's runKernel()")
     ap.add_argument("--frames-per-exchange", type=int, default=int(os.environ.get("RPT_FRAMES_PER_EXCHANGE", "1")),
                     help="N>1: frames whose planes travel in ONE gather (a collective costs as much host and launch time as a frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -353,6 +354,8 @@ def main():
         launches = []
         for rr in renderers:
             launches += end_timing(rr, steps)
+        if rank == 0 and os.environ.get("RPT_BENCH_VERBOSE") == "1":
+            print("[bench] launch durations, ms, per slot in submission order: " + " ".join(f"{x:.3f}" for x in launches), file=sys.stderr)
         return wall, launches
 
     for _ in range(max(args.warmup, 0)):

@@ -61,9 +61,9 @@ def test_bare_single_gpu_line():
     r = out["roofline"]
     assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and 0 < r["frac_blocking"] < 1
     # roofline.frac is the dominant kernel's own fraction (a launch that has the device to itself); the device-level figure with
-    # three launches overlapping is reported under a name that says so
+    # four launches overlapping is reported under a name that says so
     assert r["frac"] == r["frac_kernel_alone"] and r["launches_overlapped"] == 1.0 and "ballot_first" in r["kernel"]
-    assert 0 < r["frac_device_3_in_flight"] < 1 and r["device_in_flight"]["launches_overlapped"] >= 1.0
+    assert 0 < r["frac_device_4_in_flight"] < 1 and r["device_in_flight"]["launches_overlapped"] >= 1.0
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) < 0.02 * r["achieved"]
     assert out["ms_per_frame_blocking"] > 0 and out["frame_ms_blocking"]["median"] > 0 and out["launch_ms_in_flight"]["frames"] == 10
     assert "traffic" in r       # null unless a PMC summary of this very build is committed

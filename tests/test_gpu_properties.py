@@ -454,7 +454,7 @@ def test_bench_exchange_path_over_rccl_with_one_rank(tmp_path, split):
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["check"] == "framebuffer rows identical to the oracle", out["check"]
-    assert out["config"]["frames_in_flight"] == 3 and out["n_gpus"] == 1
+    assert out["config"]["frames_in_flight"] == 4 and out["n_gpus"] == 1
     assert out["comm"]["exchange"].startswith("ncclGather through ctypes" if exchange == "native" else "torch.distributed.gather"), out["comm"]
     if split == "auto":      # calibrate_split ran its gathers, barrier and broadcast over RCCL
         cal = out["config"]["split_calibration"]

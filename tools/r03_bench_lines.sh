@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-bench() { name=$1; shift; python bench.py --steps 50 --warmup 5 --check "$@" 2>/dev/null | tail -1 > gpurun_out/r03_bench_$name.json; echo "bench $name: $(python -c "import json;d=json.load(open('gpurun_out/r03_bench_$name.json'));r=d['roofline'];print(d['value'],d['ms_per_step'],d['ms_per_frame_blocking'],r['launch_ms'],r['frac'],r['frac_device_3_in_flight'],r['traffic'],d['animated']['ms_per_step'],d['cpu_baseline']['value'] if 'cpu_baseline' in d else None,d['check'])")"; }
+bench() { name=$1; shift; python bench.py --steps 50 --warmup 5 --check "$@" 2>/dev/null | tail -1 > gpurun_out/r03_bench_$name.json; echo "bench $name: $(python -c "import json;d=json.load(open('gpurun_out/r03_bench_$name.json'));r=d['roofline'];print(d['value'],d['ms_per_step'],d['ms_per_frame_blocking'],r['launch_ms'],r['frac'],r['device_in_flight']['frac'],r['traffic'],d['animated']['ms_per_step'],d['cpu_baseline']['value'] if 'cpu_baseline' in d else None,d['check'])")"; }
 bench bunny_3840x2160
 bench bunny_1920x1080 --width 1920 --height 1080
 bench shadows_3840x2160 --workload shadows
