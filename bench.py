@@ -393,6 +393,10 @@ def main():
     blocking_frames, blocking_launches = [], []
     if n == 1 and not force_dist:
         nb = max(1, min(args.steps, 50))
+        for _ in range(min(max(args.warmup, 0), 3)):     # untimed: the blocking call launches another kernel (43) than the frames in flight
+            frame.slots[0].r.set_objects(scene)          # above 3 Mpx did (41), and its first launch in a process is a cold one (0.3-0.4 ms)
+            frame.slots[0].r.render()
+            frame.slots[0].frames += 1
         barrier()
         r._check(r._lib.rpt_timing_begin(r._h, nb), "rpt_timing_begin")
         for _ in range(nb):
@@ -402,6 +406,8 @@ def main():
             blocking_frames.append((time.perf_counter() - t0) * 1e3)
         blocking_ms = sum(blocking_frames) / nb
         blocking_launches = end_timing(r, nb)
+        if rank == 0 and os.environ.get("RPT_BENCH_VERBOSE") == "1":
+            print("[bench] blocking launch durations, ms: " + " ".join(f"{x:.3f}" for x in blocking_launches), file=sys.stderr)
         blocking_kernel_ms = sum(blocking_launches) / max(len(blocking_launches), 1)
         frame.last = frame.slots[0]
         frame.slots[0].frames += nb

@@ -1,3 +1,6 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-timeout -k 10 500 python tools/configs.py --inflight 4 --variants 41,43,41,43 --only bunny,shadows --sizes 1280x720,1920x1080,2560x1440,3200x1800,3840x2160 --frames 40 2>&1 | grep 'variant '
+for k in 20 50; do
+RPT_BENCH_VERBOSE=1 python bench.py --steps $k --warmup 5 --no-cpu-baseline 2>gpurun_out/err.txt | tail -1 | python -c "import json,sys;d=json.loads(sys.stdin.read());print($k, d['value'], d['ms_per_step'], d['roofline']['frac'])"
+grep "blocking launch" gpurun_out/err.txt
+done
