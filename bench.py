@@ -42,13 +42,21 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# what variant 0 launches (csrc/rpt_api.hip): by whether the frame's Object[] holds a mesh
-DEFAULT_KERNEL = "rpt_render_kernel_ballot_w5 (rpt_render_async: in-wave cull, natural tile order)"
-DEFAULT_KERNEL_BLOCKING = "rpt_render_kernel_ballot_first_w5 (the blocking rpt_render: the same kernel with the mesh rows dispatched first and the latency form of the walk)"
-DEFAULT_KERNEL_SMALL = ("rpt_render_kernel_ballot_first_w5 (rpt_render_async on a context of at most RPT_LATENCY_KERNEL_MAX_PIXELS = 3 000 000 pixels: the latency kernel, "
-                        "as for the blocking call)")
-LATENCY_KERNEL_MAX_PIXELS = 3000000     # include/rpt.h
-DEFAULT_KERNEL_NO_MESH = "rpt_render_kernel_analytic_w8 (the default kernel without the octree walk compiled in: this workload's Object[] holds no mesh; 8 waves per SIMD)"
+# the product kernels by variant number (include/rpt.h); which one a launch used is read back from the library (rpt_last_variant)
+KERNELS = {
+    1: "rpt_render_kernel_v0 (the reference's layouts, no culling)",
+    3: "rpt_render_kernel_unculled_w5 (derived layouts, no culling)",
+    41: "rpt_render_kernel_ballot_w5 (in-wave cull, natural tile order: what rpt_render_async launches on contexts above 3 Mpx)",
+    43: "rpt_render_kernel_ballot_first_w5 (the same with the mesh rows dispatched first and the latency form of the walk: what the blocking rpt_render "
+        "launches, and rpt_render_async on contexts of at most RPT_LATENCY_KERNEL_MAX_PIXELS = 3 000 000 pixels)",
+    44: "rpt_render_kernel_analytic_w8 (the default kernel without the octree walk compiled in: this workload's Object[] holds no mesh; 8 waves per SIMD)",
+}
+
+
+def kernel_label(variant):
+    return KERNELS.get(variant, f"kernel variant {variant} (rpt_set_variant, include/rpt.h)")
+
+
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md): the contract roofline for this path
 
 WORKLOADS = {
@@ -386,6 +394,7 @@ def main():
     elapsed, launches = timed(args.steps)     # launch durations: HIP events on each launch's own stream
     kernel_ms = sum(launches) / max(len(launches), 1)
     kernel_sum_ms = sum(launches)
+    kernel_name = kernel_label(frame.slots[0].r.last_variant())        # what the timed launches were made with
 
     # the same frames one at a time (submit, wait, submit ...: what the reference's blocking runKernel() does) — the
     # frame LATENCY, and the launch duration without other launches sharing the device
@@ -406,6 +415,7 @@ def main():
             blocking_frames.append((time.perf_counter() - t0) * 1e3)
         blocking_ms = sum(blocking_frames) / nb
         blocking_launches = end_timing(r, nb)
+        blocking_kernel_name = kernel_label(frame.slots[0].r.last_variant())
         if rank == 0 and os.environ.get("RPT_BENCH_VERBOSE") == "1":
             print("[bench] blocking launch durations, ms: " + " ".join(f"{x:.3f}" for x in blocking_launches), file=sys.stderr)
         blocking_kernel_ms = sum(blocking_launches) / max(len(blocking_launches), 1)
@@ -435,9 +445,6 @@ def main():
         # duration / overlap, and achieved = bytes per launch / that (= bytes of all launches / wall time).
         overlap = max(1.0, kernel_sum_ms / (elapsed * 1e3)) if frame.depth > 1 else 1.0
         has_mesh = bool((np.asarray(scene.objects()["type"]) == 2).any())
-        local_pixels = W * (H if (n == 1 and not force_dist) else min(frame.local_rows, H))
-        kernel_name = ((DEFAULT_KERNEL_NO_MESH if not has_mesh else DEFAULT_KERNEL_SMALL if local_pixels <= LATENCY_KERNEL_MAX_PIXELS else DEFAULT_KERNEL) if args.variant == 0
-                       else f"kernel variant {args.variant} (rpt_set_variant, include/rpt.h)")
         achieved = alg / (kernel_ms / overlap * 1e-3) / 1e9
         out = {
             "metric": "Mrays/s (primary rays) on Scenes/bunny.txt at 3840x2160" if (args.workload, W, H) == ("bunny", 3840, 2160)
@@ -501,7 +508,7 @@ def main():
             # roofline.frac / achieved / launch_ms are the KERNEL-ALONE figures (the contract's "dominant kernel" fraction)
             rf.update({"achieved": round(a1, 2), "frac": round(a1 / HBM_PEAK_GBS, 5), "frac_kernel_alone": round(a1 / HBM_PEAK_GBS, 5),
                        "launch_ms": round(blocking_kernel_ms, 4), "launches_overlapped": 1.0,
-                       "kernel": (DEFAULT_KERNEL_BLOCKING if has_mesh else DEFAULT_KERNEL_NO_MESH) if args.variant == 0 else kernel_name,
+                       "kernel": blocking_kernel_name,
                        "regime": "one launch at a time, nothing overlapped (the blocking rpt_render): algorithmic bytes / the launch's own HIP-event duration"})
             rf["frac_blocking"] = rf["frac"]          # (round 2's name for the same number)
         else:

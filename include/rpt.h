@@ -131,6 +131,9 @@ int rpt_set_debug_rgb(rpt_ctx *ctx, void *device_ptr_or_null_or_1);
  * staging and the per-workgroup ray queue, 256+ walk experiments) — is NOT in the product library:
  * `make -C relativitypathtracer_amd/csrc diag` builds librpt_hip_diag.so with them (csrc/rpt_diag_kernels.hip.h). */
 int rpt_set_variant(rpt_ctx *ctx, int variant);
+/* The kernel (a number of the list above) this context's last launch was made with; 0 before the first launch.  What
+ * variant 0 resolved to: tests and bench.py name the kernel they measured from this, not from a copy of the rule. */
+int rpt_last_variant(const rpt_ctx *ctx);
 
 /* A culled-vs-un-culled self-check on the device.  The default kernels drop objects per wavefront from conservatively
  * sampled screen bounds and shadow rays per wavefront from segment-vs-box tests; a wrong bound would make an object vanish from

@@ -104,6 +104,7 @@ struct rpt_ctx {
     int first_tile = 0, tile_step = 1, run_log2 = 0;
     bool colour_plane = false;
     int variant = 0;
+    int last_variant = 0;                             // the kernel the last launch was made with (rpt_last_variant)
     float last_ms = 0.0f;
     bool frame_rendered = false;
     bool latency_call = false;                        // the launch in progress comes from the blocking rpt_render()
@@ -640,6 +641,7 @@ int launch(rpt_ctx *ctx) {
 #endif
     }
     RPT_HIP(ctx, hipGetLastError());
+    ctx->last_variant = v;
     return RPT_OK;
 }
 
@@ -913,6 +915,8 @@ int rpt_set_variant(rpt_ctx *ctx, int variant) {
     ctx->variant = variant;
     return RPT_OK;
 }
+
+int rpt_last_variant(const rpt_ctx *ctx) { return ctx ? ctx->last_variant : 0; }
 
 int rpt_verify_frame(rpt_ctx *ctx, unsigned long long *differing_pixels) {
     if (!ctx || !differing_pixels) return RPT_ERR_ARG;

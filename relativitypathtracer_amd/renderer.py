@@ -105,6 +105,10 @@ class Renderer:
     def set_variant(self, variant: int):
         self._check(self._lib.rpt_set_variant(self._h, int(variant)), "rpt_set_variant")
 
+    def last_variant(self) -> int:
+        """The kernel variant (include/rpt.h) the last launch of this context was made with: what variant 0 resolved to."""
+        return int(self._lib.rpt_last_variant(self._h))
+
     def verify_frame(self) -> int:
         """Pixels whose packed colour differs between the kernel a frame would get and the un-culled kernel (0 = the culls changed nothing)."""
         n = C.c_uint64(0)
