@@ -526,6 +526,7 @@ int launch_diagnostic(rpt_ctx *ctx, rptd::KernelArgs &a, dim3 grid, int tiles, i
     case 2257: hipLaunchKernelGGL(rptd::rpt_render_kernel_x257_w4, grid, dim3(256), 0, ctx->stream, a); break;
     case 2259: hipLaunchKernelGGL(rptd::rpt_render_kernel_x259_w4, grid, dim3(256), 0, ctx->stream, a); break;
     case 2263: hipLaunchKernelGGL(rptd::rpt_render_kernel_x263_w4, grid, dim3(256), 0, ctx->stream, a); break;
+    case 2573: hipLaunchKernelGGL(rptd::rpt_render_kernel_x573_w4, grid, dim3(256), 0, ctx->stream, a); break;      // the latency kernel at 4 waves per SIMD (128 VGPRs, no scratch)
     case 7:
         if (int rc = reserve(ctx, ctx->counters, 16 * sizeof(unsigned long long))) return rc;
         RPT_HIP(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 16 * sizeof(unsigned long long), ctx->stream));
@@ -614,7 +615,7 @@ int launch(rpt_ctx *ctx) {
     if (!ctx->geo->compact_ok && v != 44) v = 1;
     const bool band_first = v == 43
 #ifdef RPT_DIAGNOSTICS
-                            || v == 143 || (v >= 256 && v < 1000 && (v & 8))
+                            || v == 143 || v == 2573 || (v >= 256 && v < 1000 && (v & 8))
 #endif
         ;
     a.first_h = 0;

@@ -389,9 +389,11 @@ RPT_DEV bool octree_core_ref(const KernelArgs &a, const rpt_object &obj, const R
 //     level is spent on finding that out;
 //   * the exit face of a leaf does not depend on its triangles (getOppositeBoxSide works on the ray and the entry point alone):
 //     it is found BEFORE the triangle loop, and the neighbour's index travels while the triangles are tested;
-//   * PIPELINE (the blocking call's kernel, whose frame is as long as its longest wave): triangle records are asked for one
-//     iteration ahead.  Ten more live registers: 40 B of scratch at five waves per SIMD, worth it for latency (bunny 4K one
-//     frame at a time 0.196 -> 0.191 ms, 1080p 0.166 -> 0.158), not for throughput (0.090 -> 0.096 ms per frame in flight).
+//   * PIPELINE + FIRST (kernel 43: the blocking call, whose frame is as long as its longest wave, and small frames in flight):
+//     triangle records are asked for one iteration ahead, and a leaf's first record together with its node record
+//     (load_first_tri).  Ten more live registers: 44 B of scratch at five waves per SIMD, worth it where frames wait for
+//     latency (bunny 4K one frame at a time 0.196 -> 0.186 ms, 1080p 0.166 -> 0.151), not where the chip is full of walks
+//     (4K in flight 0.088 -> 0.095 ms per frame): profiles/r03_walk_ab.txt, r03_latency_walk_ab.txt.
 // Measured against round 2's walk (profiles/r03_walk_ab.txt): bunny 4K 0.0949 -> 0.0903 ms per frame in flight, 0.201 -> 0.191
 // one at a time; zero scratch instead of 12 B.  What was tried on top and lost is in the diagnostics build (rpt_diag_walks.hip.h).
 struct NodeRec { v4f lo, hi; int count; };
@@ -958,7 +960,7 @@ __global__ __launch_bounds__(256) void rpt_render_kernel_v0(const KernelArgs a) 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_unculled_w5(const KernelArgs a) { render_pixel_body<1>(a); }         // 3: no cull (rpt_verify_frame; the escape hatch)
 // the wave's object mask from the per-object screen rectangles by lane-parallel test + __ballot, 5 waves per SIMD (96 VGPRs, no scratch)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_w5(const KernelArgs a) { render_pixel_body<20>(a); }          // 41 = rpt_render_async
-// the same with the tile rows that hold the meshes dispatched first and the latency walk (40 B of scratch): latency, not throughput
+// the same with the tile rows that hold the meshes dispatched first and the latency walk (44 B of scratch): latency, not throughput
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_first_w5(const KernelArgs a) { render_pixel_body<23>(a); }    // 43 = the blocking rpt_render; rpt_render_async below RPT_LATENCY_KERNEL_MAX_PIXELS
 // without the octree walk compiled in, for frames whose Object[] holds no mesh: 61 VGPRs, no scratch, EIGHT waves per SIMD
 // (arch 1080p 0.0370 -> 0.0301 ms per frame in flight, cubes.txt 4K 0.0898 -> 0.0725)

@@ -1,8 +1,4 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-for st in 0 1 0 1; do for k in 20 200; do
-RPT_STAGGER=$st python bench.py --steps $k --warmup 5 --no-cpu-baseline --check 2>/dev/null | tail -1 | python -c "import json,sys;d=json.loads(sys.stdin.read());print('stagger',$st, $k, d['value'], d['ms_per_step'], d['roofline']['frac'], d['check'])"
-done; done
-for st in 0 1 0 1; do
-RPT_STAGGER=$st python tools/configs.py --inflight 4 --variants 0 --only bunny,shadows --frames 60 2>&1 | grep 'variant ' | sed "s/^/stagger $st /"
-done
+timeout -k 10 300 python -m pytest tests/test_gpu_diag_arms.py -x -q -k "2573" 2>&1 | tail -2
+timeout -k 10 400 python tools/configs.py --diag --variants 573,2573,573,2573,573,2573 --only bunny,shadows --frames 40 2>&1 | grep 'variant '
