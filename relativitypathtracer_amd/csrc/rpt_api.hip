@@ -20,6 +20,7 @@
 #include "rpt_kernels.hip.h"       /* (+ rpt_diag_walks / rpt_diag_kernels / rpt_persistent under RPT_DIAGNOSTICS) */
 #include "rpt_octree_build.hip.h"
 #include "rpt_screen_bounds.hpp"
+#include "rpt_workers.hpp"
 
 #pragma clang fp contract(off)
 
@@ -27,6 +28,13 @@
 extern "C" int rpt_launch_relaxed_kernel(int waves_per_simd, const void *args, size_t args_bytes, unsigned grid_x, unsigned grid_y, void *stream);
 
 #define RPT_STAGING_SLOTS 4
+#ifdef RPT_DIAGNOSTICS      /* RPT_HOST_PROFILE=1: where the host time of rpt_set_objects goes, summed per context and printed by rpt_destroy */
+#include <chrono>
+#define RPT_HOST_MARK(K) do { const auto now_ = std::chrono::steady_clock::now(); if (K) ctx->host_us[K] += std::chrono::duration<double, std::micro>(now_ - ctx->host_t).count(); ctx->host_t = now_; if ((K) == 5) ctx->host_calls++; } while (0)
+#else
+#define RPT_HOST_MARK(K) do { } while (0)
+#endif
+#define RPT_RECT_BATCH_MIN 8      /* screen bounds to recompute in one rpt_set_objects before the helper threads are asked (rpt_workers.hpp) */
 
 namespace {
 
@@ -105,6 +113,12 @@ struct rpt_ctx {
     bool colour_plane = false;
     int variant = 0;
     int last_variant = 0;                             // the kernel the last launch was made with (rpt_last_variant)
+    int serial = 0;                                   // creation index of this context in the process (diagnostics output)
+#ifdef RPT_DIAGNOSTICS
+    std::chrono::steady_clock::time_point host_t;     // RPT_HOST_MARK
+    double host_us[6] = {0, 0, 0, 0, 0, 0};
+    long host_calls = 0;
+#endif
     float last_ms = 0.0f;
     bool frame_rendered = false;
     bool latency_call = false;                        // the launch in progress comes from the blocking rpt_render()
@@ -372,20 +386,40 @@ void build_dobjs(const rpt_ctx *ctx, const rpt_object *objs, int count, rptd::DO
 // Per-frame image-plane rectangle of every object (rpt_screen_bounds.hpp) for the in-kernel lane-parallel cull.  A
 // rectangle is a pure function of the object's 320 bytes, the interval and (meshes) the root bounds: an object whose
 // record is byte-identical to the previous frame's (a camera at rest, a paused scene) keeps its rectangle.
+struct RectBatch {
+    rpt_ctx *ctx;
+    const rpt_object *objs;
+    rptb::Rect *out;
+    int todo[64];
+};
+void rect_batch_item(void *arg, int k) {
+    RectBatch &b = *(RectBatch *)arg;
+    const int i = b.todo[k];
+    const rpt_object &o = b.objs[i];
+    const float *root = nullptr;
+    if (o.type == RPT_MESH && o.meshIndex >= 0 && (size_t)o.meshIndex * 6 + 5 < b.ctx->geo->host_node_bounds.size())
+        root = &b.ctx->geo->host_node_bounds[(size_t)o.meshIndex * 6];
+    b.out[i] = b.ctx->rects[i] = rptb::object_rect(o, b.ctx->interval, root);
+}
 void build_rects(rpt_ctx *ctx, const rpt_object *objs, int count, rptb::Rect *out) {
     const bool comparable = ctx->rect_interval == ctx->interval && ctx->rect_geo_generation == ctx->geo->generation &&
                             ctx->rects.size() == (size_t)count && ctx->host_objects.size() == (size_t)count * sizeof(rpt_object);
     const rpt_object *prev = comparable ? (const rpt_object *)ctx->host_objects.data() : nullptr;
     ctx->rects.resize((size_t)count);
+    RectBatch batch;
+    batch.ctx = ctx;
+    batch.objs = objs;
+    batch.out = out;
+    int n_todo = 0;
     for (int i = 0; i < count; i++) {
-        const rpt_object &o = objs[i];
         if (i >= 64) { out[i] = ctx->rects[i] = rptb::full_rect(); continue; }      // the wave's mask has 64 bits: later objects are always tested
-        if (prev && std::memcmp(&prev[i], &o, sizeof o) == 0) { out[i] = ctx->rects[i]; continue; }
-        const float *root = nullptr;
-        if (o.type == RPT_MESH && o.meshIndex >= 0 && (size_t)o.meshIndex * 6 + 5 < ctx->geo->host_node_bounds.size())
-            root = &ctx->geo->host_node_bounds[(size_t)o.meshIndex * 6];
-        out[i] = ctx->rects[i] = rptb::object_rect(o, ctx->interval, root);
+        if (prev && std::memcmp(&prev[i], &objs[i], sizeof objs[i]) == 0) { out[i] = ctx->rects[i]; continue; }
+        batch.todo[n_todo++] = i;
     }
+    // the bounds that have to be recomputed: a few on the submitting thread, a batch shared with the helper threads (rpt_workers.hpp;
+    // cubes.txt, 34 moving objects: profiles/r03_host_threads.txt)
+    if (n_todo >= RPT_RECT_BATCH_MIN) rpth::Workers::instance().parallel_for(n_todo, rect_batch_item, &batch);
+    else for (int k = 0; k < n_todo; k++) rect_batch_item(&batch, k);
     ctx->rect_interval = ctx->interval;
     ctx->rect_geo_generation = ctx->geo->generation;
 }
@@ -665,6 +699,10 @@ int rpt_create(rpt_ctx **out, int device_ordinal) {
     rpt_ctx *ctx = new (std::nothrow) rpt_ctx();
     if (!ctx) return RPT_ERR_NOMEM;
     ctx->device = device_ordinal;
+    {
+        static std::atomic<int> created{0};
+        ctx->serial = created.fetch_add(1);
+    }
     ctx->geo = std::make_shared<Geometry>();
     ctx->geo->device = device_ordinal;
     if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -698,6 +736,12 @@ void rpt_destroy(rpt_ctx *ctx) {
     // work of this context may still be running on an external stream (rpt_set_stream) whose handle the caller may already
     // have destroyed: wait for the device rather than for a handle that may be dead, then free
     (void)hipDeviceSynchronize();
+#ifdef RPT_DIAGNOSTICS
+    if (ctx->host_calls > 0 && getenv("RPT_HOST_PROFILE"))
+        fprintf(stderr, "[rpt] context %d: rpt_set_objects x %ld, us per call: wait for the staging slot %.1f, copy + DObj %.1f, screen bounds %.1f, hipMemcpyAsync %.1f, hipEventRecord %.1f\n",
+                ctx->serial, ctx->host_calls, ctx->host_us[1] / ctx->host_calls, ctx->host_us[2] / ctx->host_calls, ctx->host_us[3] / ctx->host_calls,
+                ctx->host_us[4] / ctx->host_calls, ctx->host_us[5] / ctx->host_calls);
+#endif
     ctx->geo.reset();
     for (DeviceBuffer *b : {&ctx->objects, &ctx->dobjs, &ctx->counters, &ctx->wave_times, &ctx->tile_masks, &ctx->claim_counters, &ctx->verify_planes, &ctx->owned_out, &ctx->owned_plane, &ctx->owned_rgb})
         release(*b);
@@ -813,13 +857,19 @@ int rpt_set_objects(rpt_ctx *ctx, const void *objects, int count) {
     if (int rc = reserve(ctx, ctx->objects, bytes + dbytes)) return rc;
     if (bytes) {
         const int k = (int)(ctx->staging_next % RPT_STAGING_SLOTS);
+        RPT_HOST_MARK(0);
         if (ctx->staging_used & (1u << k)) RPT_HIP(ctx, hipEventSynchronize(ctx->staging_done[k]));
+        RPT_HOST_MARK(1);
         char *slot = (char *)ctx->pinned_objects + (ctx->pinned_capacity / RPT_STAGING_SLOTS) * k;
         std::memcpy(slot, objects, bytes);
         build_dobjs(ctx, (const rpt_object *)objects, count, (rptd::DObj *)(slot + bytes));
+        RPT_HOST_MARK(2);
         build_rects(ctx, (const rpt_object *)objects, count, (rptb::Rect *)(slot + bytes + (size_t)count * sizeof(rptd::DObj)));
+        RPT_HOST_MARK(3);
         RPT_HIP(ctx, hipMemcpyAsync(ctx->objects.ptr, slot, bytes + dbytes, hipMemcpyHostToDevice, ctx->stream));
+        RPT_HOST_MARK(4);
         RPT_HIP(ctx, hipEventRecord(ctx->staging_done[k], ctx->stream));
+        RPT_HOST_MARK(5);
         ctx->last_event = ctx->staging_done[k];
         ctx->staging_used |= 1u << k;
         ctx->staging_next++;

@@ -17,7 +17,7 @@ if "RPT_T0" in os.environ:
 s = Scene.from_file(name)
 s.set_camera(*cam)
 s.update_objects()
-slots = [Renderer(0) for _ in range(3)]
+slots = [Renderer(0, diag=os.environ.get("RPT_HOST_PROFILE") is not None) for _ in range(3)]
 slots[0].upload_scene(s)
 for r in slots[1:]:
     r.share_scene(slots[0])
@@ -79,3 +79,5 @@ for f in range(n):
     t_set += c - b; t_rect += g - e
 print(f"{name} animated, device idle before every call: rpt_set_objects {t_set / n * 1e6:.1f} us of which screen bounds <= {t_rect / n * 1e6:.1f} us "
       f"({len(objs)} objects, through ctypes); kernel {t_gpu / n:.4f} ms/frame one at a time")
+for r in slots:
+    r.close()          # (RPT_HOST_PROFILE=1, diagnostics library: rpt_destroy prints where rpt_set_objects spent its time)
