@@ -234,6 +234,12 @@ void rpt_free_host(void *p);
  * (in 15 floats -> out 4), 1 intersect_AABB (12 -> 5), 2 createCamRay (4 -> 3), 3 hable (3 -> 3), 4 asin / atan2 of the
  * textured-sphere (u,v) (3 -> 2), 5 the walk's pure steps: exit face of a leaf and child selection, general and fast (6 -> 12). */
 int rpt_probe(rpt_ctx *ctx, int which, const void *host_in, void *host_out, int n);
+/* Test hook, the octree walk at ray level: n rays {origin.xyz, dir.xyz} in the object space of mesh object `object_index` of the
+ * current Object[] go through the three walks of the product library — the reference's layouts (opencl_kernel.cl:200-308 as
+ * written), the throughput walk of kernel 41 and the latency walk of kernel 43 — and host_out receives 3 x 8 floats per ray:
+ * {hit, dist, normal.xyz, uv.xy, 0} per walk, the distance re-measured from the object's origin as :303-305 does.  The three
+ * must agree bit for bit (tests/test_gpu_kat.py). */
+int rpt_probe_walk(rpt_ctx *ctx, int object_index, const float *host_rays, float *host_out, int n);
 
 #ifdef __cplusplus
 }

@@ -255,17 +255,11 @@ static inline int octree_child_step(f3 *uv) {
     return childIndex;
 }
 
-/* opencl_kernel.cl:200-308 */
-static int intersect_octree(const Scene *s, const int index, const Ray4D *ray, Hit *hit) {
+/* opencl_kernel.cl:206-306: the walk from the object-space ray on; the hit is re-measured from world_origin in units of
+ * world_dirlen (:303-305).  Split off :200-205 so that rpt_oracle_octree_rays can feed it object-space rays directly. */
+static int intersect_octree_core(const Scene *s, const int index, Ray newRay, f3 world_origin, float world_dirlen, Hit *hit) {
     const rpt_object *obj = &s->objects[index];
     const rpt_octree *octrees = s->octrees;
-    STAT(octree_calls);
-    Ray newRay;
-    newRay.origin = transformPoint(obj->InvM, yzw(ray->origin));
-    newRay.dir = transformDirection(obj->InvM, yzw(ray->dir));
-    float scale = length3(newRay.dir);
-    newRay.dir = divs3(newRay.dir, scale);
-
     int currOctreeIndex = obj->meshIndex;
     f2 d;
     int closeSide, farSide;
@@ -357,10 +351,22 @@ static int intersect_octree(const Scene *s, const int index, const Ray4D *ray, H
 
         f3 objPoint = add3(newRay.origin, muls3(newRay.dir, hit->dist));
         f3 worldPoint = transformPoint(obj->M, objPoint);
-        hit->dist = length3(sub3(worldPoint, yzw(ray->origin))) / length3(yzw(ray->dir));
+        hit->dist = length3(sub3(worldPoint, world_origin)) / world_dirlen;
         return 1;
     }
     return 0;
+}
+
+/* opencl_kernel.cl:200-308 */
+static int intersect_octree(const Scene *s, const int index, const Ray4D *ray, Hit *hit) {
+    const rpt_object *obj = &s->objects[index];
+    STAT(octree_calls);
+    Ray newRay;
+    newRay.origin = transformPoint(obj->InvM, yzw(ray->origin));
+    newRay.dir = transformDirection(obj->InvM, yzw(ray->dir));
+    float scale = length3(newRay.dir);
+    newRay.dir = divs3(newRay.dir, scale);
+    return intersect_octree_core(s, index, newRay, yzw(ray->origin), length3(yzw(ray->dir)), hit);
 }
 
 /* opencl_kernel.cl:310 */
@@ -854,6 +860,44 @@ int rpt_oracle_aabb(const float *bmin, const float *bmax, const float *org, cons
 void rpt_oracle_camray(float x, float y, int w, int h, float *dir3) {
     Ray r = createCamRay(x, y, w, h);
     dir3[0] = r.dir.x; dir3[1] = r.dir.y; dir3[2] = r.dir.z;
+}
+
+/* The octree walk at ray level (tests/test_gpu_kat.py against rpt_probe_walk): n object-space rays {origin.xyz, dir.xyz} through
+ * the mesh object `object_index`; out8 per ray = {hit, dist, normal.xyz, uv.xy, 0}, the distance re-measured from (0,0,0) at unit
+ * direction length. */
+int rpt_oracle_octree_rays(const rpt_oracle_args *a, int object_index, const float *rays, float *out8, int n) {
+    if (!a || !rays || !out8 || object_index < 0 || object_index >= a->object_count) return -1;
+    Scene sc;
+    memset(&sc, 0, sizeof sc);
+    sc.objects = (const rpt_object *)a->objects;
+    sc.object_count = a->object_count;
+    sc.vertices = (const rpt_float3 *)a->vertices;
+    sc.normals = (const rpt_float3 *)a->normals;
+    sc.uvs = (const rpt_float2 *)a->uvs;
+    sc.triangles = (const uint32_t *)a->triangles;
+    sc.octrees = (const rpt_octree *)a->octrees;
+    sc.octreeTris = (const int32_t *)a->octreeTris;
+    if (sc.objects[object_index].type != RPT_MESH) return -1;
+    for (int i = 0; i < n; i++) {
+        Ray r;
+        r.origin = (f3){rays[6 * i + 0], rays[6 * i + 1], rays[6 * i + 2]};
+        r.dir = (f3){rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
+        Hit hit;
+        memset(&hit, 0, sizeof hit);
+        hit.dist = 1e20f;
+        const f3 zero = {0.0f, 0.0f, 0.0f};
+        const int h = intersect_octree_core(&sc, object_index, r, zero, 1.0f, &hit);
+        float *o = out8 + 8 * (size_t)i;
+        o[0] = h ? 1.0f : 0.0f;
+        o[1] = h ? hit.dist : 0.0f;
+        o[2] = h ? hit.normal.x : 0.0f;
+        o[3] = h ? hit.normal.y : 0.0f;
+        o[4] = h ? hit.normal.z : 0.0f;
+        o[5] = h ? hit.uv.x : 0.0f;
+        o[6] = h ? hit.uv.y : 0.0f;
+        o[7] = 0.0f;
+    }
+    return 0;
 }
 
 /* out4 = {side, uv'.xyz} of getOppositeBoxSide; out4b = {childIndex, uv'.xyz} of the octree child step */

@@ -48,6 +48,9 @@ int  rpt_oracle_aabb(const float *bmin, const float *bmax, const float *org, con
 void rpt_oracle_camray(float x, float y, int w, int h, float *dir3);
 void rpt_oracle_hable(const float *in3, float *out3);
 void rpt_oracle_walk_steps(const float *scaledDir3, const float *uv3, float *out4, float *out4b);
+/* opencl_kernel.cl:206-306 on n object-space rays {origin.xyz, dir.xyz} through mesh object `object_index`; out8 per ray =
+ * {hit, dist, normal.xyz, uv.xy, 0} (distance re-measured from the origin of the object's frame at unit direction length). */
+int rpt_oracle_octree_rays(const rpt_oracle_args *a, int object_index, const float *rays, float *out8, int n);
 void rpt_oracle_asin_atan2(float a, float y, float x, float *out2);   /* out2 = {asin(a), atan2(y, x)} as the oracle defines them */
 
 #ifdef __cplusplus

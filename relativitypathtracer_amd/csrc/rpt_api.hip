@@ -1258,6 +1258,49 @@ int rpt_probe(rpt_ctx *ctx, int which, const void *host_in, void *host_out, int 
     return rc;
 }
 
+int rpt_probe_walk(rpt_ctx *ctx, int object_index, const float *host_rays, float *host_out, int n) {
+    if (!ctx || !host_rays || !host_out || n <= 0) return RPT_ERR_ARG;
+    if (!ctx->scene_uploaded || ctx->object_count <= 0) return fail(ctx, RPT_ERR_STATE, "rpt_probe_walk before rpt_upload_scene / rpt_set_objects");
+    if (object_index < 0 || object_index >= ctx->object_count || ctx->host_objects.size() < (size_t)(object_index + 1) * sizeof(rpt_object) ||
+        ((const rpt_object *)ctx->host_objects.data())[object_index].type != RPT_MESH)
+        return fail(ctx, RPT_ERR_ARG, "rpt_probe_walk: not a mesh object");
+    if (!ctx->geo->compact_ok) return fail(ctx, RPT_ERR_STATE, "rpt_probe_walk: this octree has no derived layout (children not consecutive)");
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    rptd::KernelArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.dnodes = (const rptd::DNode *)ctx->geo->dnodes.ptr;
+    a.dtris = (const rptd::DTri *)ctx->geo->dtris.ptr;
+    a.links = (const int *)ctx->geo->dlinks.ptr;
+    a.first_tris = (const rptd::DTri *)ctx->geo->dfirst.ptr;
+    a.top_count = ctx->geo->top_count;
+    a.dobjs = (const rptd::DObj *)((const char *)ctx->objects.ptr + (size_t)ctx->object_count * sizeof(rpt_object));
+    a.objects = (const rpt_object *)ctx->objects.ptr;
+    a.vertices = (const rpt_float3 *)ctx->geo->vertices.ptr;
+    a.normals = (const rpt_float3 *)ctx->geo->normals.ptr;
+    a.uvs = (const rpt_float2 *)ctx->geo->uvs.ptr;
+    a.triangles = (const uint32_t *)ctx->geo->triangles.ptr;
+    a.octrees = (const rpt_octree *)ctx->geo->octrees.ptr;
+    a.octreeTris = (const int32_t *)ctx->geo->octreeTris.ptr;
+    a.object_count = ctx->object_count;
+    float *d_in = nullptr, *d_out = nullptr;
+    RPT_HIP(ctx, hipMalloc((void **)&d_in, sizeof(float) * 6 * (size_t)n));
+    if (hipMalloc((void **)&d_out, sizeof(float) * 24 * (size_t)n) != hipSuccess) {
+        (void)hipFree(d_in);
+        return fail(ctx, RPT_ERR_NOMEM, "rpt_probe_walk: hipMalloc");
+    }
+    int rc = RPT_OK;
+    if (hipMemcpy(d_in, host_rays, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) rc = RPT_ERR_DEVICE;
+    if (!rc) {
+        hipLaunchKernelGGL(rptd::rpt_probe_walk_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a, object_index, d_in, d_out, n);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+            hipMemcpy(host_out, d_out, sizeof(float) * 24 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(ctx, RPT_ERR_DEVICE, "rpt_probe_walk: device error");
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------

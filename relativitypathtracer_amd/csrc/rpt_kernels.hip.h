@@ -1104,6 +1104,39 @@ __global__ void rpt_probe_kernel(int which, const float *in, float *out, int n) 
     }
 }
 
+// Known-answer probe of the octree walk at RAY level: every ray (object-space origin and direction) through the three walks the
+// product library holds — the reference's layouts (octree_core_ref), the throughput walk (octree_walk<false, false>) and the latency
+// walk (octree_walk<true, true>) — with the hit re-measured from the origin (0, 0, 0) at unit direction length.  8 floats per walk
+// and ray: hit flag, dist, normal.xyz, uv.xy, 0.
+__global__ __launch_bounds__(256) void rpt_probe_walk_kernel(const KernelArgs a, int object, const float *rays, float *out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r;
+    r.origin = mk3(rays[6 * i + 0], rays[6 * i + 1], rays[6 * i + 2]);
+    r.dir = mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+    const rpt_object &obj = a.objects[object];
+    const int root = a.dobjs[object].root;
+    for (int w = 0; w < 3; w++) {
+        Hit hit;
+        hit.dist = 1e20f;
+        hit.normal = mk3(0.0f, 0.0f, 0.0f);
+        hit.uv.x = hit.uv.y = 0.0f;
+        hit.object = -1;
+        const bool h = w == 0 ? octree_core_ref(a, obj, r, mk3(0.0f, 0.0f, 0.0f), 1.0f, hit)
+                     : w == 1 ? octree_walk<false, false>(a, obj, root, r, mk3(0.0f, 0.0f, 0.0f), 1.0f, hit)
+                              : octree_walk<true, true>(a, obj, root, r, mk3(0.0f, 0.0f, 0.0f), 1.0f, hit);
+        float *o = out + ((size_t)i * 3 + w) * 8;
+        o[0] = h ? 1.0f : 0.0f;
+        o[1] = h ? hit.dist : 0.0f;
+        o[2] = h ? hit.normal.x : 0.0f;
+        o[3] = h ? hit.normal.y : 0.0f;
+        o[4] = h ? hit.normal.z : 0.0f;
+        o[5] = h ? hit.uv.x : 0.0f;
+        o[6] = h ? hit.uv.y : 0.0f;
+        o[7] = 0.0f;
+    }
+}
+
 #endif  /* !RPT_RELAXED_FP */
 
 }  // namespace rptd

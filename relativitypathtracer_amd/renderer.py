@@ -220,6 +220,15 @@ class Renderer:
         self._check(self._lib.rpt_probe(self._h, which, inputs.ctypes.data, out.ctypes.data, n), "rpt_probe")
         return out
 
+    def probe_walk(self, object_index: int, rays: np.ndarray) -> np.ndarray:
+        """rays (n, 6) = object-space origin and direction -> (n, 3, 8): {hit, dist, normal.xyz, uv.xy, 0} from the reference-layout
+        walk, the throughput walk and the latency walk (include/rpt.h, rpt_probe_walk)."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32)
+        n = rays.shape[0]
+        out = np.empty((n, 3, 8), dtype=np.float32)
+        self._check(self._lib.rpt_probe_walk(self._h, int(object_index), rays.ctypes.data, out.ctypes.data, n), "rpt_probe_walk")
+        return out
+
 
 def render_scene(scene: Scene, width: int, height: int, device: int = 0, debug_rgb: bool = False):
     """Convenience: upload, render one frame, read back. Returns (pixels, rgb-or-None)."""

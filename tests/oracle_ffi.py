@@ -62,6 +62,8 @@ def lib() -> C.CDLL:
         l.rpt_oracle_hable.argtypes = [FP, FP]
         l.rpt_oracle_walk_steps.restype = None
         l.rpt_oracle_walk_steps.argtypes = [FP, FP, FP, FP]
+        l.rpt_oracle_octree_rays.restype = C.c_int
+        l.rpt_oracle_octree_rays.argtypes = [C.POINTER(OracleArgs), C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         l.rpt_oracle_asin_atan2.restype = None
         l.rpt_oracle_asin_atan2.argtypes = [C.c_float, C.c_float, C.c_float, FP]
         _lib = l
@@ -105,6 +107,21 @@ def render(scene, width: int, height: int, *, rows=None, threads: int = 0, want_
         raise RuntimeError(f"rpt_oracle_render failed: {rc}")
     stats = {n: getattr(st, n) for n in STAT_FIELDS} if st is not None else None
     return pixels, rgb, stats
+
+
+def octree_rays(scene, object_index: int, rays: np.ndarray) -> np.ndarray:
+    """opencl_kernel.cl:206-306 on object-space rays (n, 6) through mesh object `object_index`: (n, 8) = hit, dist, normal.xyz, uv.xy, 0."""
+    d = scene.desc()
+    a = OracleArgs()
+    a.objects, a.object_count = d.objects, d.object_count
+    a.vertices, a.normals, a.uvs = d.vertices, d.normals, d.uvs
+    a.triangles, a.octrees, a.octreeTris = d.triangles, d.octrees, d.octreeTris
+    rays = np.ascontiguousarray(rays, dtype=np.float32)
+    out = np.empty((rays.shape[0], 8), dtype=np.float32)
+    rc = lib().rpt_oracle_octree_rays(C.byref(a), int(object_index), rays.ctypes.data, out.ctypes.data, rays.shape[0])
+    if rc != 0:
+        raise RuntimeError(f"rpt_oracle_octree_rays failed: {rc}")
+    return out
 
 
 PIXEL_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("rgba", "u1", (4,)), ("unspecified", "<u4")])
