@@ -131,6 +131,12 @@ int rpt_set_debug_rgb(rpt_ctx *ctx, void *device_ptr_or_null_or_1);
  * staging and the per-workgroup ray queue, 256+ walk experiments) — is NOT in the product library:
  * `make -C relativitypathtracer_amd/csrc diag` builds librpt_hip_diag.so with them (csrc/rpt_diag_kernels.hip.h). */
 int rpt_set_variant(rpt_ctx *ctx, int variant);
+/* MSAASAMPLES of opencl_kernel.cl:7 — a compile-time constant of the reference, 1 as shipped; a maintainer who edits it gets
+ * n x n camera rays per pixel at (x + i/n, y + j/n), summed and divided by n^2 before the tonemap (:641-648).  1 (default) = the
+ * kernels above; 2..8 = the multi-sample form of the default kernel (in-wave cull; reported by rpt_last_variant as 46) or, with
+ * variant 3, of the un-culled kernel (47); other variants refuse.  No reference output exists for any value but 1: the
+ * arithmetic is the oracle's (tests/test_gpu_parity.py), its pin is the one-sample path's. */
+int rpt_set_msaa(rpt_ctx *ctx, int samples_per_axis);
 /* The kernel (a number of the list above) this context's last launch was made with; 0 before the first launch.  What
  * variant 0 resolved to: tests and bench.py name the kernel they measured from this, not from a copy of the rule. */
 int rpt_last_variant(const rpt_ctx *ctx);

@@ -719,12 +719,28 @@ static inline uint8_t to_u8(float c) {  /* (unsigned char)(c * 255), saturating,
 
 /* opencl_kernel.cl:620-660, one work item */
 static void render_pixel(const Scene *s, const f3 white_point, const float ambient, const int width,
-                         const int height, unsigned int work_item_id, rpt_pixel *output, float *rgb_out) {
+                         const int height, const int msaa, unsigned int work_item_id, rpt_pixel *output, float *rgb_out) {
     unsigned int x_coord = work_item_id % width;
     unsigned int y_coord = work_item_id / width;
 
-    Ray camray = createCamRay((float)x_coord, (float)y_coord, width, height);
-    f3 finalcolor = trace(s, ambient, &camray);
+    f3 finalcolor;
+    if (msaa <= 1) {
+        /* MSAASAMPLES = 1 (opencl_kernel.cl:7), the reference as shipped: x + 0/1 = x, 0 + c = c, c / 1 = c — the loop of
+         * :642-648 leaves trace()'s colour as it is, so it is not spelled out (the golden screenshots pin THIS path) */
+        Ray camray = createCamRay((float)x_coord, (float)y_coord, width, height);
+        finalcolor = trace(s, ambient, &camray);
+    } else {
+        /* opencl_kernel.cl:641-648 with MSAASAMPLES = msaa (a compile-time constant a maintainer may edit; no reference output
+         * exists for any value but 1: parity unpinned beyond the arithmetic below) */
+        finalcolor = F3(0.0f, 0.0f, 0.0f);
+        for (int y = 0; y < msaa; y++) {
+            for (int x = 0; x < msaa; x++) {
+                Ray camray = createCamRay((float)x_coord + (float)x / msaa, (float)y_coord + (float)y / msaa, width, height);
+                finalcolor = add3(finalcolor, trace(s, ambient, &camray));
+            }
+        }
+        finalcolor = divs3(finalcolor, (float)(msaa * msaa));
+    }
     finalcolor = div3(hable(finalcolor), hable(white_point));
     finalcolor = F3(cl_min(finalcolor.x, 1.0f), cl_min(finalcolor.y, 1.0f), cl_min(finalcolor.z, 1.0f));
 
@@ -776,7 +792,7 @@ static void *worker_main(void *p) {
         for (int y = r0; y < r1; y++) {
             for (int x = 0; x < a->width; x++) {
                 unsigned int id = (unsigned int)y * (unsigned int)a->width + (unsigned int)x;
-                render_pixel(&job->scene, wp, a->ambient, a->width, a->height, id,
+                render_pixel(&job->scene, wp, a->ambient, a->width, a->height, a->msaa, id,
                              (rpt_pixel *)a->out_pixels, a->out_rgb);
             }
         }

@@ -30,6 +30,7 @@ typedef struct rpt_oracle_args {
     int32_t interval;         /*                                      arg 13 */
     void *out_pixels;         /* rpt_pixel[width*height] or NULL      arg 14 */
     float *out_rgb;           /* float[3*width*height] tonemapped RGB before packing, or NULL */
+    int32_t msaa;             /* MSAASAMPLES of opencl_kernel.cl:7 (a compile-time constant there); 0 or 1 = the reference as shipped */
 } rpt_oracle_args;
 
 /* Work counters (whole call, summed over threads); names follow SURVEY.md §8a. */

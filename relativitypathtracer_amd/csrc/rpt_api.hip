@@ -113,6 +113,7 @@ struct rpt_ctx {
     bool colour_plane = false;
     int variant = 0;
     int last_variant = 0;                             // the kernel the last launch was made with (rpt_last_variant)
+    int msaa = 1;                                     // MSAASAMPLES (rpt_set_msaa)
     int serial = 0;                                   // creation index of this context in the process (diagnostics output)
 #ifdef RPT_DIAGNOSTICS
     std::chrono::steady_clock::time_point host_t;     // RPT_HOST_MARK
@@ -657,7 +658,14 @@ int launch(rpt_ctx *ctx) {
         int ty0 = 0, ty1 = -1;
         if (mesh_band(ctx, a.aspect, tiles, ty0, ty1) && ty0 > 0 && (ty1 - ty0 + 1) * 2 < tiles) { a.first_ty = ty0; a.first_h = ty1 - ty0 + 1; }
     }
+    a.msaa = ctx->msaa;
+    if (ctx->msaa > 1) {       // MSAASAMPLES > 1: the multi-sample form of the default kernel (46), or of the un-culled one (47)
+        if (v != 3 && v != 41 && v != 43 && v != 44) return fail(ctx, RPT_ERR_ARG, "rpt_set_msaa > 1 is implemented for the default kernels and variant 3 (derived octree layouts)");
+        v = v == 3 ? 47 : 46;
+    }
     switch (v) {
+    case 46: hipLaunchKernelGGL(rptd::rpt_render_kernel_msaa_w5, grid, dim3(256), 0, ctx->stream, a); break;
+    case 47: hipLaunchKernelGGL(rptd::rpt_render_kernel_msaa_unculled_w5, grid, dim3(256), 0, ctx->stream, a); break;
     case 1: hipLaunchKernelGGL(rptd::rpt_render_kernel_v0, grid, dim3(256), 0, ctx->stream, a); break;
     case 3: hipLaunchKernelGGL(rptd::rpt_render_kernel_unculled_w5, grid, dim3(256), 0, ctx->stream, a); break;
     case 41: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w5, grid, dim3(256), 0, ctx->stream, a); break;
@@ -968,6 +976,13 @@ int rpt_set_variant(rpt_ctx *ctx, int variant) {
 }
 
 int rpt_last_variant(const rpt_ctx *ctx) { return ctx ? ctx->last_variant : 0; }
+
+int rpt_set_msaa(rpt_ctx *ctx, int samples_per_axis) {
+    if (!ctx) return RPT_ERR_ARG;
+    if (samples_per_axis < 1 || samples_per_axis > 8) return fail(ctx, RPT_ERR_ARG, "rpt_set_msaa: 1..8 samples per axis");
+    ctx->msaa = samples_per_axis;
+    return RPT_OK;
+}
 
 int rpt_verify_frame(rpt_ctx *ctx, unsigned long long *differing_pixels) {
     if (!ctx || !differing_pixels) return RPT_ERR_ARG;

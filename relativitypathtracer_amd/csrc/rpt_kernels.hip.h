@@ -90,6 +90,7 @@ struct KernelArgs {
     // dispatch order (V == 23): the strips [first_sx, first_sx + first_w) x [first_ty, first_ty + first_h) — where the meshes
     // are, i.e. where the frame's longest waves live — are handed out FIRST, the rest in natural order; first_w = 0: off
     int first_sx, first_ty, first_w, first_h;
+    int msaa;                       // MSAASAMPLES of opencl_kernel.cl:7 when it is not 1 (rpt_set_msaa; the kernels of render_pixel_body_msaa only)
     float bg_mapped[3];      // min(hable(background)/hable(white_point), 1): what every miss pixel maps to
     float ambient;
     float hable_wp[3];       // hable(white_point), host-computed
@@ -954,6 +955,53 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
 #endif
 }
 
+// opencl_kernel.cl:641-648 with MSAASAMPLES = a.msaa > 1 (a compile-time constant of the reference, 1 as shipped; rpt_set_msaa): a.msaa^2
+// camera rays per pixel at (x + sx/n, y + sy/n), colours summed in the reference's order (a miss contributes the background of :565)
+// and divided by n^2 before the tonemap.  A function of its own so that the one-sample kernels stay what they are.  V = 20: the
+// wave's object mask as in render_pixel_body — the tile it is tested against is grown by a pixel and a half, the samples stay
+// within one pixel; V = 1: no cull (what rpt_verify_frame compares with).
+template <int V>
+RPT_DEV void render_pixel_body_msaa(const KernelArgs &a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int tile_row = (int)blockIdx.y;
+    const int strip = (int)blockIdx.x;
+    const int row_in_tile = lane >> 3;
+    const int x_coord = strip * 32 + wave * 8 + (lane & 7);
+    const int local_row = tile_row * RPT_TILE_ROWS + row_in_tile;
+    const int global_tile = (tile_row >> a.run_log2) * a.tile_step + a.first_tile + (tile_row & ((1 << a.run_log2) - 1));
+    const int y_coord = global_tile * RPT_TILE_ROWS + row_in_tile;
+    unsigned long long object_mask = ~0ull;
+    if (culled_variant<V>()) object_mask = wave_object_mask(a, strip * 32 + wave * 8, global_tile * RPT_TILE_ROWS);
+    if (x_coord >= a.width || y_coord >= a.height) return;
+    const bool any = !culled_variant<V>() || object_mask != 0 || a.object_count > 64;
+    const int n = a.msaa;
+    f3 sum = mk3(0.0f, 0.0f, 0.0f);
+    for (int sy = 0; sy < n; sy++) {
+        for (int sx = 0; sx < n; sx++) {
+            f3 c = mk3(0.15f, 0.15f, 0.25f);
+            if (any) {
+                const f3 camdir = createCamRayDir((float)x_coord + (float)sx / (float)n, (float)y_coord + (float)sy / (float)n, a.width, a.height, a.aspect);
+                f3 traced;
+                if (trace<V>(a, camdir, object_mask, traced)) c = traced;
+            }
+            sum = sum + c;
+        }
+    }
+    const float n2 = (float)(n * n);
+    sum = mk3(sum.x / n2, sum.y / n2, sum.z / n2);
+    f3 mapped;
+    const uint32_t packed = tonemap_pack(a, sum, mapped);
+    const size_t id = (size_t)y_coord * a.width + x_coord;
+    if (a.out16) store_pixel(a.out16, id, __float_as_uint((float)x_coord), __float_as_uint((float)y_coord), packed, 0u);
+    if (a.plane) __builtin_nontemporal_store(packed, a.plane + (size_t)local_row * a.width + x_coord);
+    if (a.debug_rgb) {
+        a.debug_rgb[3 * id + 0] = mapped.x;
+        a.debug_rgb[3 * id + 1] = mapped.y;
+        a.debug_rgb[3 * id + 2] = mapped.z;
+    }
+}
+
 #ifndef RPT_RELAXED_FP    /* rpt_relaxed.hip instantiates its own two kernels and nothing else from here on */
 // Product kernels (rpt_set_variant; the number in the comment is the variant).
 __global__ __launch_bounds__(256) void rpt_render_kernel_v0(const KernelArgs a) { render_pixel_body<0>(a); }                                                              // 1: any valid octree
@@ -965,6 +1013,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 // without the octree walk compiled in, for frames whose Object[] holds no mesh: 61 VGPRs, no scratch, EIGHT waves per SIMD
 // (arch 1080p 0.0370 -> 0.0301 ms per frame in flight, cubes.txt 4K 0.0898 -> 0.0725)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_analytic_w8(const KernelArgs a) { render_pixel_body<24>(a); }        // 44
+
+// MSAASAMPLES > 1 (rpt_set_msaa): culled and un-culled; rpt_last_variant reports them as 46 / 47
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_msaa_w5(const KernelArgs a) { render_pixel_body_msaa<20>(a); }            // 46
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_msaa_unculled_w5(const KernelArgs a) { render_pixel_body_msaa<1>(a); }    // 47
 
 #ifdef RPT_DIAGNOSTICS
 }  // namespace rptd

@@ -105,6 +105,10 @@ class Renderer:
     def set_variant(self, variant: int):
         self._check(self._lib.rpt_set_variant(self._h, int(variant)), "rpt_set_variant")
 
+    def set_msaa(self, samples_per_axis: int):
+        """MSAASAMPLES of opencl_kernel.cl:7 (1 = the reference as shipped)."""
+        self._check(self._lib.rpt_set_msaa(self._h, int(samples_per_axis)), "rpt_set_msaa")
+
     def last_variant(self) -> int:
         """The kernel variant (include/rpt.h) the last launch of this context was made with: what variant 0 resolved to."""
         return int(self._lib.rpt_last_variant(self._h))

@@ -24,7 +24,7 @@ class OracleArgs(C.Structure):
         ("textures", C.c_void_p), ("texture_bytes", C.c_uint64),
         ("white_point", C.c_float * 3), ("ambient", C.c_float),
         ("width", C.c_int32), ("height", C.c_int32), ("interval", C.c_int32),
-        ("out_pixels", C.c_void_p), ("out_rgb", C.c_void_p),
+        ("out_pixels", C.c_void_p), ("out_rgb", C.c_void_p), ("msaa", C.c_int32),
     ]
 
 
@@ -71,7 +71,7 @@ def lib() -> C.CDLL:
 
 
 def render(scene, width: int, height: int, *, rows=None, threads: int = 0, want_rgb: bool = True,
-           want_stats: bool = False, objects: np.ndarray | None = None, interval: int | None = None):
+           want_stats: bool = False, objects: np.ndarray | None = None, interval: int | None = None, msaa: int = 1):
     """Render `scene` (a relativitypathtracer_amd.Scene whose objects are up to date) on the CPU oracle.
 
     Returns (pixels[H*W] structured 16 B, rgb[H,W,3] float32 or None, stats dict or None).
@@ -92,6 +92,7 @@ def render(scene, width: int, height: int, *, rows=None, threads: int = 0, want_
     a.ambient = p["ambient"]
     a.width, a.height = width, height
     a.interval = p["interval"] if interval is None else interval
+    a.msaa = msaa
     pixels = np.zeros(width * height, dtype=PIXEL_DTYPE)
     a.out_pixels = pixels.ctypes.data
     rgb = None

@@ -63,6 +63,43 @@ def test_frame_matches_oracle(renderer, name, variant):
         assert d.max() <= 1, f"{name}: packed bytes differ by more than one LSB"
 
 
+@pytest.mark.parametrize("msaa", [2, 3])
+@pytest.mark.parametrize("name", ["bunny", "shadows", "arch", "cubes", "soccer"])
+def test_msaa_matches_oracle(name, msaa):
+    """MSAASAMPLES (opencl_kernel.cl:7, :641-648) other than the shipped 1: rpt_set_msaa's kernels — n x n rays per pixel at
+    (x + i/n, y + j/n), summed in the reference's order, a miss contributing the background, divided by n^2 before the tonemap —
+    against the oracle's restatement of the same loop, float RGB bit for bit, culled (46) and un-culled (47), on a frame whose
+    size is no multiple of the tile; the cull changes nothing (rpt_verify_frame).  (No reference output exists for n > 1: what
+    pins these frames to the reference is the one-sample path.)"""
+    from relativitypathtracer_amd.renderer import Renderer, RenderError
+    W, H = (333, 190) if name != "soccer" else (250, 141)
+    scene = load_config(name)
+    opx, orgb, _ = oracle_ffi.render(scene, W, H, msaa=msaa)
+    opx1, _, _ = oracle_ffi.render(scene, W, H, want_rgb=False)
+    assert not np.array_equal(opx["rgba"], opx1["rgba"])            # more samples do change edges
+    r = Renderer(0)
+    try:
+        r.set_msaa(msaa)
+        for variant, kernel in ((0, 46), (3, 47)):
+            px, rgb = _render_gpu(r, scene, W, H, variant)
+            assert r.last_variant() == kernel
+            assert np.array_equal(rgb.view(np.uint32), orgb.view(np.uint32)), f"{name} msaa {msaa} variant {variant}: float RGB not bit-identical"
+            assert np.array_equal(px["rgba"], opx["rgba"]) and np.array_equal(px["x"], opx["x"]) and np.array_equal(px["y"], opx["y"])
+        r.set_variant(0)
+        assert r.verify_frame() == 0
+        r.set_variant(1)
+        with pytest.raises(RenderError):
+            r.render()                       # the reference-layout kernel has no multi-sample form
+        r.set_variant(0)
+        with pytest.raises(RenderError):
+            r.set_msaa(0)
+        r.set_msaa(1)
+        px, _ = _render_gpu(r, scene, W, H, 0)
+        assert np.array_equal(px["rgba"], opx1["rgba"]) and r.last_variant() in (43, 44)
+    finally:
+        r.close()
+
+
 def test_odd_resolution_guard(renderer):
     """Width/height that are not multiples of the 32x8 strip: the reference has no bounds guard."""
     scene = load_config("shadows")
