@@ -333,6 +333,39 @@ def test_animation_pipelined_frames(renderer):
         assert np.array_equal(got, opx["rgba"]), f"frame {f}"
 
 
+def test_multi_sample_shards_reassemble_to_the_single_context_frame():
+    """rpt_set_msaa with rpt_set_rows: a 3-way shard of a 2 x 2-sample frame (the multi-sample kernel writing colour planes) is the
+    frame of one context, and that frame is the oracle's."""
+    import torch
+    from relativitypathtracer_amd.renderer import Renderer
+    scene = load_config("bunny")
+    W, H, world = 640, 360, 3
+    r = Renderer(0)
+    try:
+        r.set_msaa(2)
+        _setup(r, scene, W, H)
+        r.render()
+        assert r.last_variant() == 46
+        want = r.read_framebuffer()
+        opx, _, _ = oracle_ffi.render(scene, W, H, want_rgb=False, msaa=2)
+        assert np.array_equal(want["rgba"], opx["rgba"])
+        words = rdist.plane_words(W, H, world)
+        gathered = torch.zeros((world, words), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for rank in range(world):
+            r.set_rows(rank, world, True)
+            r.set_plane_output(gathered[rank].data_ptr())
+            r.render()
+        out = torch.zeros(W * H * 4, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        r.scatter_colour_plane(gathered.data_ptr(), out.data_ptr(), W, H, world, words)
+        r.sync()
+        got = out.cpu().numpy().view(want.dtype)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    finally:
+        r.close()
+
+
 def test_which_kernel_a_frame_gets():
     """include/rpt.h, rpt_set_variant(0): the blocking call gets the latency kernel (43); rpt_render_async gets it on contexts of at
     most RPT_LATENCY_KERNEL_MAX_PIXELS — a rank's share of a sharded frame counts, not the frame — and the throughput kernel (41)
