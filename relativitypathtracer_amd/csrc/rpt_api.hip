@@ -315,18 +315,20 @@ int build_derived_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
             }
         }
     }
-    if (tris.size() > (size_t)0x7fffffff) return RPT_OK;
-    // (16 B of slack behind the triangle records: the cooperative 16-B staging loads of the persistent kernels never start past the
-    // last record, but keep the buffer's end away from them all the same)
-    if (int rc = upload(ctx, g.dnodes, nodes.data(), nodes.size() * sizeof(rptd::DNode))) return rc;
-    if (int rc = upload(ctx, g.dlinks, links.data(), links.size() * sizeof(int32_t))) return rc;
-    if (int rc = upload(ctx, g.dtris, tris.data(), tris.size() * sizeof(rptd::DTri))) return rc;
-    {   // the first record of every list again, by node index (load_first_tri)
+    if (tris.size() > (size_t)RPT_NODE_BEGIN_MASK) return RPT_OK;      // (16.7 M triangle references: the general kernel takes such a scene)
+    {   // the first record of every list again, by node index (load_first_tri) — before leafBegin gets the count packed into it
         std::vector<rptd::DTri> first(n);
         std::memset(first.data(), 0, first.size() * sizeof(rptd::DTri));
         for (size_t k = 0; k < n; k++) if (nodes[k].leafCount > 0) first[k] = tris[(size_t)nodes[k].leafBegin];
         if (int rc = upload(ctx, g.dfirst, first.data(), first.size() * sizeof(rptd::DTri))) return rc;
     }
+    for (size_t k = 0; k < n; k++)          // leafBegin | min(leafCount, 255) << 24: see load_node_rec
+        nodes[k].leafBegin = (int)((unsigned int)nodes[k].leafBegin | ((unsigned int)(nodes[k].leafCount < 255 ? nodes[k].leafCount : 255) << 24));
+    // (16 B of slack behind the triangle records: the cooperative 16-B staging loads of the persistent kernels never start past the
+    // last record, but keep the buffer's end away from them all the same)
+    if (int rc = upload(ctx, g.dnodes, nodes.data(), nodes.size() * sizeof(rptd::DNode))) return rc;
+    if (int rc = upload(ctx, g.dlinks, links.data(), links.size() * sizeof(int32_t))) return rc;
+    if (int rc = upload(ctx, g.dtris, tris.data(), tris.size() * sizeof(rptd::DTri))) return rc;
     g.compact_ok = true;
     return RPT_OK;
 }
@@ -556,7 +558,7 @@ int launch_diagnostic(rpt_ctx *ctx, rptd::KernelArgs &a, dim3 grid, int tiles, i
     }
     case 61: hipLaunchKernelGGL(rptd::rpt_render_kernel_queue_w5, grid, dim3(256), 0, ctx->stream, a); break;
     RPT_LAUNCH_X(256) RPT_LAUNCH_X(257) RPT_LAUNCH_X(259) RPT_LAUNCH_X(261) RPT_LAUNCH_X(263) RPT_LAUNCH_X(265) RPT_LAUNCH_X(269)
-    RPT_LAUNCH_X(273) RPT_LAUNCH_X(277) RPT_LAUNCH_X(285) RPT_LAUNCH_X(305) RPT_LAUNCH_X(317) RPT_LAUNCH_X(337) RPT_LAUNCH_X(349) RPT_LAUNCH_X(401) RPT_LAUNCH_X(785) RPT_LAUNCH_X(529) RPT_LAUNCH_X(541) RPT_LAUNCH_X(561) RPT_LAUNCH_X(573)
+    RPT_LAUNCH_X(273) RPT_LAUNCH_X(277) RPT_LAUNCH_X(285) RPT_LAUNCH_X(305) RPT_LAUNCH_X(317) RPT_LAUNCH_X(337) RPT_LAUNCH_X(349) RPT_LAUNCH_X(401) RPT_LAUNCH_X(785) RPT_LAUNCH_X(529) RPT_LAUNCH_X(541) RPT_LAUNCH_X(561) RPT_LAUNCH_X(573) RPT_LAUNCH_X(589)
     case 1257: hipLaunchKernelGGL(rptd::rpt_render_kernel_x257_w6, grid, dim3(256), 0, ctx->stream, a); break;
     case 2257: hipLaunchKernelGGL(rptd::rpt_render_kernel_x257_w4, grid, dim3(256), 0, ctx->stream, a); break;
     case 2259: hipLaunchKernelGGL(rptd::rpt_render_kernel_x259_w4, grid, dim3(256), 0, ctx->stream, a); break;

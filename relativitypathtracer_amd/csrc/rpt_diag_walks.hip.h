@@ -31,7 +31,7 @@ template <> struct NodeRef<1> {
         r = side == 5 ? q3.z : r;
         return r;
     }
-    RPT_DEV int tri_begin(const KernelArgs &) const { return __float_as_int(hi.w); }
+    RPT_DEV int tri_begin(const KernelArgs &) const { return __float_as_int(hi.w) & RPT_NODE_BEGIN_MASK; }
     RPT_DEV int tri_count(const KernelArgs &) const { return q2.x; }
     RPT_DEV void tri(const KernelArgs &a, int k, f3 &A, f3 &v0v1, f3 &v0v2, int &id) const {
         const v4f *p = reinterpret_cast<const v4f *>(a.dtris + k);
@@ -253,7 +253,7 @@ template <int F>
 RPT_DEV bool octree_walk_x(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin,
                             float world_dirlen, Hit &hit) {
     int curr = root;
-    NodeRec rec = load_node_rec(a, curr);
+    NodeRec rec = load_node_rec<false>(a, curr);
     f2 d;
     int closeSide, farSide;
     f3 nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z), nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
@@ -267,7 +267,7 @@ RPT_DEV bool octree_walk_x(const KernelArgs &a, const rpt_object &obj, int root,
                 curr = (link & RPT_LINK_CHILD_MASK) + octree_child_step_fast(uv);
                 link = a.dnodes[curr].link;
             }
-            rec = load_node_rec(a, curr);
+            rec = load_node_rec<false>(a, curr);
         }
         nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
         nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
@@ -293,11 +293,11 @@ RPT_DEV bool octree_walk_x(const KernelArgs &a, const rpt_object &obj, int root,
                 if ((F & 16) && ((link >> (24 + k)) & 1)) break;          // the link says this child is a leaf: no lookup
                 link = (F & 16) ? a.links[curr] : a.dnodes[curr].link;
             }
-            rec = load_node_rec(a, curr);
+            rec = load_node_rec<false>(a, curr);
             nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
             nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
         }
-        int i = __float_as_int(rec.hi.w);
+        int i = __float_as_int(rec.hi.w) & RPT_NODE_BEGIN_MASK;
         const int trisEnd = i + rec.count;
         // the way out, before the triangles
         farSide = getOppositeBoxSide(plan, uv);
@@ -313,11 +313,11 @@ RPT_DEV bool octree_walk_x(const KernelArgs &a, const rpt_object &obj, int root,
                     TriRec nxt = cur;
                     if (i + 1 < trisEnd) nxt = load_tri_rec(a, i + 1);
                     test_tri_rec_x<(F & 64) != 0>(cur, newRay, hit, hitTri, didHit);
-                    if ((F & 2) && !fetched) { if (next != -1) nrec = load_node_rec(a, next); fetched = true; }
+                    if ((F & 2) && !fetched) { if (next != -1) nrec = load_node_rec<false>(a, next); fetched = true; }
                     cur = nxt;
                 }
             } else if (F & 2) {
-                if (next != -1) nrec = load_node_rec(a, next);
+                if (next != -1) nrec = load_node_rec<false>(a, next);
             }
         } else if (F & 128) {     // two records per round trip
             for (; i + 1 < trisEnd; i += 2) {
@@ -331,14 +331,14 @@ RPT_DEV bool octree_walk_x(const KernelArgs &a, const rpt_object &obj, int root,
                 test_tri_rec_x<(F & 64) != 0>(load_tri_rec(a, i), newRay, hit, hitTri, didHit);
                 i++;
             }
-            if (F & 2) { if (next != -1) nrec = load_node_rec(a, next); }
+            if (F & 2) { if (next != -1) nrec = load_node_rec<false>(a, next); }
             for (; i < trisEnd; i++) test_tri_rec_x<(F & 64) != 0>(load_tri_rec(a, i), newRay, hit, hitTri, didHit);
         }
         uv = nmin + uv * (nmax - nmin);
         const bool stop = exit_is_past_hit(uv - newRay.origin, hit.dist, didHit);
         if (stop || next == -1) break;
         curr = next;
-        rec = (F & 2) ? nrec : load_node_rec(a, curr);
+        rec = (F & 2) ? nrec : load_node_rec<false>(a, curr);
     }
     if (F & 32) __builtin_amdgcn_s_setprio(0);
     if (!didHit) return false;
@@ -406,7 +406,7 @@ RPT_DEV bool octree_walk_nbrec(const KernelArgs &a, const rpt_object &obj, int r
             nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
             nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
         }
-        int i = __float_as_int(rec.hi.w);
+        int i = __float_as_int(rec.hi.w) & RPT_NODE_BEGIN_MASK;
         const int trisEnd = i + rec.q2.x;
         farSide = getOppositeBoxSide(plan, uv);
         int next = rec.q2.y;
@@ -472,7 +472,8 @@ RPT_DEV void diag_wave_end(const KernelArgs &a, DiagWaveClock c) {
 template <int V> RPT_DEV constexpr bool diag_walk_selected() { return V == 2 || V == 4 || V == 5 || V == 10 || V == 120 || V == 121 || V == 122 || V == 123 || V >= 256; }
 template <int V>
 RPT_DEV bool diag_walk(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin, float world_dirlen, Hit &hit) {
-    if (V == 561 || V == 573) return octree_walk<true, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);
+    if (V == 561 || V == 573) return octree_walk<true, true, false>(a, obj, root, newRay, world_origin, world_dirlen, hit);    // = kernel 43's walk
+    if (V == 589) return octree_walk<true, true, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);                // 573 WITH the packed leaf count (lost: r03_packed_count_ab.txt)
     if (V == 529 || V == 541) return octree_walk_nbrec<V == 541>(a, obj, root, newRay, world_origin, world_dirlen, hit);
     if (V >= 256) return octree_walk_x<((V == 785 ? 273 : V) & 247)>(a, obj, root, newRay, world_origin, world_dirlen, hit);
     return octree_core_diag<V>(a, obj, root, newRay, world_origin, world_dirlen, hit);

@@ -397,13 +397,23 @@ RPT_DEV bool octree_core_ref(const KernelArgs &a, const rpt_object &obj, const R
 //     (4K in flight 0.088 -> 0.095 ms per frame): profiles/r03_walk_ab.txt, r03_latency_walk_ab.txt.
 // Measured against round 2's walk (profiles/r03_walk_ab.txt): bunny 4K 0.0949 -> 0.0903 ms per frame in flight, 0.201 -> 0.191
 // one at a time; zero scratch instead of 12 B.  What was tried on top and lost is in the diagnostics build (rpt_diag_walks.hip.h).
+// hi.w of a node record = leafBegin | min(leafCount, 255) << 24 (build_derived_geometry): the count of a leaf's list travels with the
+// box, so a node visit of the throughput walk is two 16-B loads, not three instructions; a list of 255 or more reads the full count
+// from its own field, and so does the latency walk always (PACKED_COUNT = false: see mesh_walk).
+#define RPT_NODE_BEGIN_MASK 0x00ffffff
 struct NodeRec { v4f lo, hi; int count; };
+template <bool PACKED_COUNT = true>
 RPT_DEV NodeRec load_node_rec(const KernelArgs &a, int i) {
     const v4f *p = reinterpret_cast<const v4f *>(a.dnodes + i);
     NodeRec r;
     r.lo = p[0];
     r.hi = p[1];
-    r.count = a.dnodes[i].leafCount;
+    if (PACKED_COUNT) {
+        r.count = (int)(__float_as_uint(r.hi.w) >> 24);
+        if (r.count == 255) r.count = a.dnodes[i].leafCount;
+    } else {
+        r.count = a.dnodes[i].leafCount;
+    }
     return r;
 }
 struct TriRec { v4f t0, t1; float e2z; int tri; };
@@ -456,11 +466,11 @@ RPT_DEV int descend_to_leaf(const KernelArgs &a, int link, f3 &uv) {
 }
 
 // PIPELINE: triangle records one iteration ahead.  FIRST (with PIPELINE): the first record of a leaf comes with its node record.
-template <bool PIPELINE, bool FIRST>
+template <bool PIPELINE, bool FIRST, bool PACKED_COUNT = true>
 RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin,
                          float world_dirlen, Hit &hit) {
     int curr = root;
-    NodeRec rec = load_node_rec(a, curr);
+    NodeRec rec = load_node_rec<PACKED_COUNT>(a, curr);
     f2 d;
     int closeSide, farSide;
     f3 nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z), nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
@@ -470,7 +480,7 @@ RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, c
         uv = (newRay.origin - nmin) / (nmax - nmin);
         if (__float_as_int(rec.lo.w) != -1) {
             curr = descend_to_leaf(a, __float_as_int(rec.lo.w), uv);
-            rec = load_node_rec(a, curr);
+            rec = load_node_rec<PACKED_COUNT>(a, curr);
         }
         nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
         nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
@@ -488,12 +498,12 @@ RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, c
         uv = (uv - nmin) / (nmax - nmin);
         if (__float_as_int(rec.lo.w) != -1) {
             curr = descend_to_leaf(a, __float_as_int(rec.lo.w), uv);
-            rec = load_node_rec(a, curr);
+            rec = load_node_rec<PACKED_COUNT>(a, curr);
             if (FIRST) first = load_first_tri(a, curr);
             nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
             nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
         }
-        int i = __float_as_int(rec.hi.w);
+        int i = __float_as_int(rec.hi.w) & RPT_NODE_BEGIN_MASK;
         const int trisEnd = i + rec.count;
         farSide = getOppositeBoxSide(plan, uv);             // the way out, before the triangles
         const int next = a.dnodes[curr].nb[farSide];
@@ -513,7 +523,7 @@ RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, c
         uv = nmin + uv * (nmax - nmin);
         if (exit_is_past_hit(uv - newRay.origin, hit.dist, didHit) || next == -1) break;
         curr = next;
-        rec = load_node_rec(a, curr);
+        rec = load_node_rec<PACKED_COUNT>(a, curr);
         if (FIRST) first = load_first_tri(a, curr);
     }
     if (!didHit) return false;
@@ -535,7 +545,9 @@ RPT_DEV bool mesh_walk(const KernelArgs &a, const rpt_object &obj, int i, const 
     if (diag_walk_selected<V>()) return diag_walk<V>(a, obj, a.dobjs[i].root, newRay, world_origin, world_dirlen, hit);
 #endif
     if (V == 0) return octree_core_ref(a, obj, newRay, world_origin, world_dirlen, hit);
-    return octree_walk<V == 23, V == 23>(a, obj, a.dobjs[i].root, newRay, world_origin, world_dirlen, hit);
+    // (the packed leaf count pays in the throughput walk — one instruction less per node visit, -0.5...-1 % — and costs the latency
+    // walk 2-4.5 %, whose count then sits behind a shift and a compare instead of arriving beside the box: profiles/r03_packed_count_ab.txt)
+    return octree_walk<V == 23, V == 23, V != 23>(a, obj, a.dobjs[i].root, newRay, world_origin, world_dirlen, hit);
 }
 
 RPT_DEV float max3(f3 v) { return cl_max(cl_max(v.x, v.y), v.z); }   // opencl_kernel.cl:310
@@ -1175,8 +1187,8 @@ __global__ __launch_bounds__(256) void rpt_probe_walk_kernel(const KernelArgs a,
         hit.uv.x = hit.uv.y = 0.0f;
         hit.object = -1;
         const bool h = w == 0 ? octree_core_ref(a, obj, r, mk3(0.0f, 0.0f, 0.0f), 1.0f, hit)
-                     : w == 1 ? octree_walk<false, false>(a, obj, root, r, mk3(0.0f, 0.0f, 0.0f), 1.0f, hit)
-                              : octree_walk<true, true>(a, obj, root, r, mk3(0.0f, 0.0f, 0.0f), 1.0f, hit);
+                     : w == 1 ? octree_walk<false, false, true>(a, obj, root, r, mk3(0.0f, 0.0f, 0.0f), 1.0f, hit)
+                              : octree_walk<true, true, false>(a, obj, root, r, mk3(0.0f, 0.0f, 0.0f), 1.0f, hit);
         float *o = out + ((size_t)i * 3 + w) * 8;
         o[0] = h ? 1.0f : 0.0f;
         o[1] = h ? hit.dist : 0.0f;

@@ -87,7 +87,7 @@ RPT_DEV void load_box(const KernelArgs &a, int idx, f3 &nmin, f3 &nmax, int &lin
     nmin = mk3(lo.x, lo.y, lo.z);
     nmax = mk3(hi.x, hi.y, hi.z);
     link = __float_as_int(lo.w);
-    leafBegin = __float_as_int(hi.w);
+    leafBegin = __float_as_int(hi.w) & RPT_NODE_BEGIN_MASK;
 }
 
 // opencl_kernel.cl:200-286 for the lanes whose `alive` is set, called by ALL lanes of the wave in uniform control flow.
