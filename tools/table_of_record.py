@@ -85,8 +85,9 @@ if "--write" in sys.argv:
     h16 = next(iter(hashes))[:16]
     path = os.path.join(ROOT, "DESIGN.md")
     text = open(path).read()
-    text = re.sub(r"(<!-- table-of-record rows:[^\n]*-->\n).*?(<!-- /table-of-record rows -->)", lambda m: m.group(1) + "\n".join(out_rows) + "\n" + m.group(2), text, flags=re.S)
-    text = re.sub(r"(<!-- counter rows:[^\n]*-->\n).*?(<!-- /counter rows -->)", lambda m: m.group(1) + "\n".join(counter_rows) + "\n" + m.group(2), text, flags=re.S)
+    # the markers stand before the table's header and after its last row (a comment between rows would end the table)
+    text = re.sub(r"(<!-- table-of-record rows:[^\n]*-->\n\|[^\n]*\n\|---[^\n]*\n).*?(<!-- /table-of-record rows -->)", lambda m: m.group(1) + "\n".join(out_rows) + "\n" + m.group(2), text, flags=re.S)
+    text = re.sub(r"(<!-- counter rows:[^\n]*-->\n\|[^\n]*\n\|---[^\n]*\n).*?(<!-- /counter rows -->)", lambda m: m.group(1) + "\n".join(counter_rows) + "\n" + m.group(2), text, flags=re.S)
     text = re.sub(r"(### 6\.1 Table of record — library `)[0-9a-f]+(…`)", lambda m: m.group(1) + h16 + m.group(2), text)
     open(path, "w").write(text)
     path = os.path.join(ROOT, "profiles", "README.md")
