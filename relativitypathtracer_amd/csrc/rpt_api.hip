@@ -34,6 +34,7 @@ extern "C" int rpt_launch_relaxed_kernel(int waves_per_simd, const void *args, s
 #else
 #define RPT_HOST_MARK(K) do { } while (0)
 #endif
+#define RPT_GRID_ROOTS_MAX 64     /* octree roots that get a descend_from_root table (16 KB each) */
 #define RPT_RECT_BATCH_MIN 8      /* screen bounds to recompute in one rpt_set_objects before the helper threads are asked (rpt_workers.hpp) */
 
 namespace {
@@ -53,6 +54,8 @@ struct Geometry {
     DeviceBuffer vertices, normals, uvs, triangles, octrees, octreeTris, textures;
     DeviceBuffer dnodes, dtris, dlinks;       // derived layouts (rpt_kernels.hip.h)
     DeviceBuffer dfirst;                      // first triangle record of every node's list, by node index (the latency walk)
+    DeviceBuffer dgrids;                      // 16^3 cells per octree root: where four child steps from the root end (descend_from_root)
+    int grid_roots = 0;
     bool compact_ok = false;                  // derived octree layout usable (children consecutive)
     unsigned long long generation = 0;        // unique per upload (the rectangle cache of a context names its geometry by this, not by address)
     std::vector<int> node_new_index;          // reference node index -> index in the derived, breadth-first numbering
@@ -63,7 +66,7 @@ struct Geometry {
     size_t vertex_count = 0, normal_count = 0, uv_count = 0, triangle_words = 0, octree_count = 0, octree_tri_count = 0;
     ~Geometry() {
         (void)hipSetDevice(device);
-        for (DeviceBuffer *b : {&vertices, &normals, &uvs, &triangles, &octrees, &octreeTris, &textures, &dnodes, &dtris, &dlinks, &dfirst}) release(*b);
+        for (DeviceBuffer *b : {&vertices, &normals, &uvs, &triangles, &octrees, &octreeTris, &textures, &dnodes, &dtris, &dlinks, &dfirst, &dgrids}) release(*b);
     }
 };
 
@@ -241,6 +244,7 @@ int build_derived_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
     Geometry &g = *ctx->geo;
     g.compact_ok = false;
     g.top_count = 0;
+    g.grid_roots = 0;
     g.node_new_index.clear();
     if (s.octree_count == 0) {
         g.compact_ok = true;
@@ -322,6 +326,28 @@ int build_derived_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
         for (size_t k = 0; k < n; k++) if (nodes[k].leafCount > 0) first[k] = tris[(size_t)nodes[k].leafBegin];
         if (int rc = upload(ctx, g.dfirst, first.data(), first.size() * sizeof(rptd::DTri))) return rc;
     }
+#ifdef RPT_DIAGNOSTICS
+    {   // descend_from_root's tables (measurement arms 593 / 605): for every root (the first records of the breadth-first numbering; at most RPT_GRID_ROOTS_MAX of
+        // them) and every cell of the 16^3 grid over its box, the node that four child steps reach — or the leaf met before
+        size_t roots = 0;
+        for (size_t i = 0; i < n; i++) roots += is_child[i] ? 0 : 1;
+        if (roots > (size_t)RPT_GRID_ROOTS_MAX) roots = RPT_GRID_ROOTS_MAX;
+        std::vector<int32_t> grids(roots * RPT_GRID_CELLS);
+        for (size_t r = 0; r < roots; r++)
+            for (int cx = 0; cx < 16; cx++) for (int cy = 0; cy < 16; cy++) for (int cz = 0; cz < 16; cz++) {
+                int node = (int)r, lvl = 0;
+                while (nodes[(size_t)node].link != -1 && lvl < RPT_GRID_LEVELS) {
+                    const int sh = RPT_GRID_LEVELS - 1 - lvl;
+                    const int child = (((cx >> sh) & 1) << 2) | (((cy >> sh) & 1) << 1) | ((cz >> sh) & 1);      // opencl_kernel.cl:257: z + 2 y + 4 x
+                    node = (nodes[(size_t)node].link & RPT_LINK_CHILD_MASK) + child;
+                    lvl++;
+                }
+                grids[r * RPT_GRID_CELLS + (size_t)((cx * 16 + cy) * 16 + cz)] = node | (lvl << 24) | ((nodes[(size_t)node].link == -1 ? 1 : 0) << 28);
+            }
+        if (int rc = upload(ctx, g.dgrids, grids.data(), grids.size() * sizeof(int32_t))) return rc;
+        g.grid_roots = (int)roots;
+    }
+#endif
     for (size_t k = 0; k < n; k++)          // leafBegin | min(leafCount, 255) << 24: see load_node_rec
         nodes[k].leafBegin = (int)((unsigned int)nodes[k].leafBegin | ((unsigned int)(nodes[k].leafCount < 255 ? nodes[k].leafCount : 255) << 24));
     // (16 B of slack behind the triangle records: the cooperative 16-B staging loads of the persistent kernels never start past the
@@ -558,7 +584,7 @@ int launch_diagnostic(rpt_ctx *ctx, rptd::KernelArgs &a, dim3 grid, int tiles, i
     }
     case 61: hipLaunchKernelGGL(rptd::rpt_render_kernel_queue_w5, grid, dim3(256), 0, ctx->stream, a); break;
     RPT_LAUNCH_X(256) RPT_LAUNCH_X(257) RPT_LAUNCH_X(259) RPT_LAUNCH_X(261) RPT_LAUNCH_X(263) RPT_LAUNCH_X(265) RPT_LAUNCH_X(269)
-    RPT_LAUNCH_X(273) RPT_LAUNCH_X(277) RPT_LAUNCH_X(285) RPT_LAUNCH_X(305) RPT_LAUNCH_X(317) RPT_LAUNCH_X(337) RPT_LAUNCH_X(349) RPT_LAUNCH_X(401) RPT_LAUNCH_X(785) RPT_LAUNCH_X(529) RPT_LAUNCH_X(541) RPT_LAUNCH_X(561) RPT_LAUNCH_X(573) RPT_LAUNCH_X(589)
+    RPT_LAUNCH_X(273) RPT_LAUNCH_X(277) RPT_LAUNCH_X(285) RPT_LAUNCH_X(305) RPT_LAUNCH_X(317) RPT_LAUNCH_X(337) RPT_LAUNCH_X(349) RPT_LAUNCH_X(401) RPT_LAUNCH_X(785) RPT_LAUNCH_X(529) RPT_LAUNCH_X(541) RPT_LAUNCH_X(561) RPT_LAUNCH_X(573) RPT_LAUNCH_X(589) RPT_LAUNCH_X(605) RPT_LAUNCH_X(593)
     case 1257: hipLaunchKernelGGL(rptd::rpt_render_kernel_x257_w6, grid, dim3(256), 0, ctx->stream, a); break;
     case 2257: hipLaunchKernelGGL(rptd::rpt_render_kernel_x257_w4, grid, dim3(256), 0, ctx->stream, a); break;
     case 2259: hipLaunchKernelGGL(rptd::rpt_render_kernel_x259_w4, grid, dim3(256), 0, ctx->stream, a); break;
@@ -594,6 +620,10 @@ int launch(rpt_ctx *ctx) {
     a.dtris = (const rptd::DTri *)ctx->geo->dtris.ptr;
     a.links = (const int *)ctx->geo->dlinks.ptr;
     a.first_tris = (const rptd::DTri *)ctx->geo->dfirst.ptr;
+#ifdef RPT_DIAGNOSTICS
+    a.root_grids = (const int *)ctx->geo->dgrids.ptr;
+    a.grid_roots = ctx->geo->grid_roots;
+#endif
     a.top_count = ctx->geo->top_count;
     a.dobjs = (const rptd::DObj *)((const char *)ctx->objects.ptr + (size_t)ctx->object_count * sizeof(rpt_object));
     a.objects = (const rpt_object *)ctx->objects.ptr;
@@ -1289,6 +1319,10 @@ int rpt_probe_walk(rpt_ctx *ctx, int object_index, const float *host_rays, float
     a.dtris = (const rptd::DTri *)ctx->geo->dtris.ptr;
     a.links = (const int *)ctx->geo->dlinks.ptr;
     a.first_tris = (const rptd::DTri *)ctx->geo->dfirst.ptr;
+#ifdef RPT_DIAGNOSTICS
+    a.root_grids = (const int *)ctx->geo->dgrids.ptr;
+    a.grid_roots = ctx->geo->grid_roots;
+#endif
     a.top_count = ctx->geo->top_count;
     a.dobjs = (const rptd::DObj *)((const char *)ctx->objects.ptr + (size_t)ctx->object_count * sizeof(rpt_object));
     a.objects = (const rpt_object *)ctx->objects.ptr;

@@ -473,6 +473,8 @@ template <int V> RPT_DEV constexpr bool diag_walk_selected() { return V == 2 || 
 template <int V>
 RPT_DEV bool diag_walk(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin, float world_dirlen, Hit &hit) {
     if (V == 561 || V == 573) return octree_walk<true, true, false>(a, obj, root, newRay, world_origin, world_dirlen, hit);    // = kernel 43's walk
+    if (V == 605) return octree_walk<true, true, false, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);           // 573 WITH the root table (descend_from_root; lost)
+    if (V == 593) return octree_walk<false, false, true, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);          // kernel 41's walk WITH the root table (level)
     if (V == 589) return octree_walk<true, true, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);                // 573 WITH the packed leaf count (lost: r03_packed_count_ab.txt)
     if (V == 529 || V == 541) return octree_walk_nbrec<V == 541>(a, obj, root, newRay, world_origin, world_dirlen, hit);
     if (V >= 256) return octree_walk_x<((V == 785 ? 273 : V) & 247)>(a, obj, root, newRay, world_origin, world_dirlen, hit);

@@ -103,6 +103,10 @@ struct KernelArgs {
     const DObj *dobjs;
     const int *links;               // DNode::link of every node again, 4 B apart: what a descent reads per level
     const DTri *first_tris;         // per node: the first triangle record of its leaf list again, addressable by the NODE's index
+#ifdef RPT_DIAGNOSTICS
+    const int *root_grids;          // per octree root (the first grid_roots derived nodes): 16^3 cells -> node | level << 24 | leaf << 28 (arms 593 / 605)
+    int grid_roots;
+#endif
     int top_count;                  // nodes [0, top_count) are the forest's top levels (whole levels, <= RPT_TOP_MAX)
     // persistent kernels (rpt_persistent.hip.h): the band of tile rows that holds the meshes (first_ty, first_h above) is
     // claimed tile by tile from per-queue counters, the other rows are dealt statically in runs of RPT_SKY_RUN tiles
@@ -466,7 +470,41 @@ RPT_DEV int descend_to_leaf(const KernelArgs &a, int link, f3 &uv) {
 }
 
 // PIPELINE: triangle records one iteration ahead.  FIRST (with PIPELINE): the first record of a leaf comes with its node record.
-template <bool PIPELINE, bool FIRST, bool PACKED_COUNT = true>
+// MEASUREMENT ARM (ROOT_GRID; diagnostics library, arms 593 / 605; exact, and not adopted: profiles/r03_root_grid_ab.txt — the link words of
+// an octree's top levels are a handful of hot addresses, a 16-KB table read per lane is not).
+// The descent from a ROOT (opencl_kernel.cl:256-261 at the start of a walk) in one lookup.  For 0 <= c < 1.5 the child step of a
+// component is a bit extraction (octree_child_step_fast): with m = min(c, 1 - eps), the child bit at level k is bit k of m's binary
+// fraction and the re-normalised coordinate after L levels is frac(2^L m) — every product and difference exact.  A component in
+// (-2^-10, 0) — an entry point a rounding below its face — selects child 0 at every level (round(c) = -0) and is doubled per level
+// (2 fmod(c, 0.5) = 2 c, exact): truncation gives both.  So the cell (trunc(16 m.x), trunc(16 m.y), trunc(16 m.z)) of a 16^3 table
+// names the node four levels down, or the leaf above that level with the level it lives on, and uv leaves as L single child steps
+// would leave it; deeper trees continue from there.  Any other component (NaN, >= 1.5, more negative) takes the serial descent.
+#define RPT_GRID_LEVELS 4
+#define RPT_GRID_CELLS 4096
+#ifndef RPT_DIAGNOSTICS
+RPT_DEV int descend_from_root(const KernelArgs &a, int, int link, f3 &uv) { return descend_to_leaf(a, link, uv); }     // (the product library has no tables)
+#else
+RPT_DEV int descend_from_root(const KernelArgs &a, int root, int link, f3 &uv) {
+    const float lo = -0x1p-10f;
+    const bool ok = (uv.x > lo) & (uv.x < 1.5f) & (uv.y > lo) & (uv.y < 1.5f) & (uv.z > lo) & (uv.z < 1.5f) & (root < a.grid_roots);
+    if (!ok) return descend_to_leaf(a, link, uv);
+    const float top = 1.0f - RPT_EPSILON;
+    const float mx = top < uv.x ? top : uv.x, my = top < uv.y ? top : uv.y, mz = top < uv.z ? top : uv.z;
+    const int cx = (int)(mx * 16.0f), cy = (int)(my * 16.0f), cz = (int)(mz * 16.0f);
+    const int e = a.root_grids[root * RPT_GRID_CELLS + ((cx * 16 + cy) * 16 + cz)];
+    const float s = (float)(1 << ((e >> 24) & 7));
+    const float x = mx * s, y = my * s, z = mz * s;
+    uv.x = x - (float)(int)x;
+    uv.y = y - (float)(int)y;
+    uv.z = z - (float)(int)z;
+    int node = e & RPT_LINK_CHILD_MASK;
+    if (!((e >> 28) & 1)) node = descend_to_leaf(a, a.links[node], uv);       // an inner node four levels down: the tree goes deeper here
+    return node;
+}
+
+#endif
+
+template <bool PIPELINE, bool FIRST, bool PACKED_COUNT = true, bool ROOT_GRID = false>
 RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin,
                          float world_dirlen, Hit &hit) {
     int curr = root;
@@ -479,7 +517,7 @@ RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, c
     if (d.x < 0) {   // ray starts inside the root: descend to the leaf holding the origin
         uv = (newRay.origin - nmin) / (nmax - nmin);
         if (__float_as_int(rec.lo.w) != -1) {
-            curr = descend_to_leaf(a, __float_as_int(rec.lo.w), uv);
+            curr = ROOT_GRID ? descend_from_root(a, root, __float_as_int(rec.lo.w), uv) : descend_to_leaf(a, __float_as_int(rec.lo.w), uv);
             rec = load_node_rec<PACKED_COUNT>(a, curr);
         }
         nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
@@ -497,7 +535,8 @@ RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, c
         nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
         uv = (uv - nmin) / (nmax - nmin);
         if (__float_as_int(rec.lo.w) != -1) {
-            curr = descend_to_leaf(a, __float_as_int(rec.lo.w), uv);
+            // (only a walk's first step can stand on a root: nobody's neighbour link points at one)
+            curr = (ROOT_GRID && steps == 1) ? descend_from_root(a, root, __float_as_int(rec.lo.w), uv) : descend_to_leaf(a, __float_as_int(rec.lo.w), uv);
             rec = load_node_rec<PACKED_COUNT>(a, curr);
             if (FIRST) first = load_first_tri(a, curr);
             nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
@@ -547,7 +586,7 @@ RPT_DEV bool mesh_walk(const KernelArgs &a, const rpt_object &obj, int i, const 
     if (V == 0) return octree_core_ref(a, obj, newRay, world_origin, world_dirlen, hit);
     // (the packed leaf count pays in the throughput walk — one instruction less per node visit, -0.5...-1 % — and costs the latency
     // walk 2-4.5 %, whose count then sits behind a shift and a compare instead of arriving beside the box: profiles/r03_packed_count_ab.txt)
-    return octree_walk<V == 23, V == 23, V != 23>(a, obj, a.dobjs[i].root, newRay, world_origin, world_dirlen, hit);
+    return octree_walk<V == 23, V == 23, V != 23, false>(a, obj, a.dobjs[i].root, newRay, world_origin, world_dirlen, hit);
 }
 
 RPT_DEV float max3(f3 v) { return cl_max(cl_max(v.x, v.y), v.z); }   // opencl_kernel.cl:310
