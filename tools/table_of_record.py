@@ -93,5 +93,15 @@ if "--write" in sys.argv:
     path = os.path.join(ROOT, "profiles", "README.md")
     text = open(path).read()
     text = re.sub(r"(Library of record: `librpt_hip.so` sha256 `)[0-9a-f]+(…`)", lambda m: m.group(1) + h16 + m.group(2), text)
+    d = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_bench_bunny_3840x2160.json")))
+    r = d["roofline"]
+    line = (f"(bunny 4K, {d['config'].get('frames_in_flight', 4)} frames in flight: {sp(d['value'])} Mrays/s, {d['ms_per_step']:.4f} ms/step; "
+            f"{d['ms_per_frame_blocking']:.4f} ms one at a time; kernel alone {r['launch_ms']:.4f} ms = {r['frac']:.4f} of the roofline; HBM traffic "
+            f"{r['traffic'] / 1e6:.1f} MB vs {r['algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic; animated {d['animated']['ms_per_step']:.4f} ms/step; "
+            f"CPU oracle {d['cpu_baseline']['value']:.1f} Mrays/s on {d['cpu_baseline']['cores']} threads)")
+    text = re.sub(r"\(bunny 4K, \w+ frames in flight: [^)]*threads\)", lambda m: line, text)
+    rp = rocprof_blocking_ms("bunny_3840x2160")
+    if rp:
+        text = re.sub(r"(the cold first one included\) )[0-9.]+( µs average)", lambda m: m.group(1) + f"{rp * 1e3:.1f}" + m.group(2), text)
     open(path, "w").write(text)
     print("written: DESIGN.md sections 6.1 / 6.2, profiles/README.md")
