@@ -372,7 +372,7 @@ RPT_DEV NodeRecN load_node_rec_n(const KernelArgs &a, int i) {
     r.q3 = reinterpret_cast<const v4i *>(p)[3];
     return r;
 }
-template <bool PIPELINE>
+template <bool PIPELINE, bool FIRST = false>
 RPT_DEV bool octree_walk_nbrec(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin,
                                float world_dirlen, Hit &hit) {
     int curr = root;
@@ -396,6 +396,8 @@ RPT_DEV bool octree_walk_nbrec(const KernelArgs &a, const rpt_object &obj, int r
     const ExitPlan plan = makeExitPlan(normalize(newRay.dir / (nmax - nmin)));
     bool didHit = false;
     int hitTri = 0;
+    TriRec first;
+    if (FIRST) first = load_first_tri(a, curr);
     for (int steps = 1; steps <= RPT_MAX_LEAF_STEPS; steps++) {
         nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
         nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
@@ -403,6 +405,7 @@ RPT_DEV bool octree_walk_nbrec(const KernelArgs &a, const rpt_object &obj, int r
         if (__float_as_int(rec.lo.w) != -1) {
             curr = descend_to_leaf(a, __float_as_int(rec.lo.w), uv);
             rec = load_node_rec_n(a, curr);
+            if (FIRST) first = load_first_tri(a, curr);
             nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
             nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
         }
@@ -417,7 +420,7 @@ RPT_DEV bool octree_walk_nbrec(const KernelArgs &a, const rpt_object &obj, int r
         next = farSide == 5 ? rec.q3.z : next;
         if (PIPELINE) {
             if (i < trisEnd) {
-                TriRec cur = load_tri_rec(a, i);
+                TriRec cur = FIRST ? first : load_tri_rec(a, i);
                 for (; i < trisEnd; i++) {
                     TriRec nxt = cur;
                     if (i + 1 < trisEnd) nxt = load_tri_rec(a, i + 1);
@@ -432,6 +435,7 @@ RPT_DEV bool octree_walk_nbrec(const KernelArgs &a, const rpt_object &obj, int r
         if (exit_is_past_hit(uv - newRay.origin, hit.dist, didHit) || next == -1) break;
         curr = next;
         rec = load_node_rec_n(a, curr);
+        if (FIRST) first = load_first_tri(a, curr);
     }
     if (!didHit) return false;
     mesh_hit_finish(a, obj, newRay.origin, newRay.dir, hitTri, world_origin, world_dirlen, hit);
@@ -476,6 +480,7 @@ RPT_DEV bool diag_walk(const KernelArgs &a, const rpt_object &obj, int root, con
     if (V == 605) return octree_walk<true, true, false, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);           // 573 WITH the root table (descend_from_root; lost)
     if (V == 593) return octree_walk<false, false, true, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);          // kernel 41's walk WITH the root table (level)
     if (V == 589) return octree_walk<true, true, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);                // 573 WITH the packed leaf count (lost: r03_packed_count_ab.txt)
+    if (V == 621) return octree_walk_nbrec<true, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);      // 541 + a leaf's first triangle with its node: a whole step's data in one round trip
     if (V == 529 || V == 541) return octree_walk_nbrec<V == 541>(a, obj, root, newRay, world_origin, world_dirlen, hit);
     if (V >= 256) return octree_walk_x<((V == 785 ? 273 : V) & 247)>(a, obj, root, newRay, world_origin, world_dirlen, hit);
     return octree_core_diag<V>(a, obj, root, newRay, world_origin, world_dirlen, hit);
