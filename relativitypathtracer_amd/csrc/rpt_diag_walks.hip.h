@@ -476,10 +476,12 @@ RPT_DEV void diag_wave_end(const KernelArgs &a, DiagWaveClock c) {
 template <int V> RPT_DEV constexpr bool diag_walk_selected() { return V == 2 || V == 4 || V == 5 || V == 10 || V == 120 || V == 121 || V == 122 || V == 123 || V >= 256; }
 template <int V>
 RPT_DEV bool diag_walk(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin, float world_dirlen, Hit &hit) {
-    if (V == 561 || V == 573) return octree_walk<true, true, false>(a, obj, root, newRay, world_origin, world_dirlen, hit);    // = kernel 43's walk
-    if (V == 605) return octree_walk<true, true, false, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);           // 573 WITH the root table (descend_from_root; lost)
-    if (V == 593) return octree_walk<false, false, true, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);          // kernel 41's walk WITH the root table (level)
-    if (V == 589) return octree_walk<true, true, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);                // 573 WITH the packed leaf count (lost: r03_packed_count_ab.txt)
+    if (V == 561 || V == 573) return octree_walk<true, true, false, false, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);    // = kernel 43's walk
+    if (V == 605) return octree_walk<true, true, false, true, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);           // 573 WITH the root table (descend_from_root; lost)
+    if (V == 593) return octree_walk<false, false, true, true, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);          // kernel 41's walk WITH the root table (level)
+    if (V == 589) return octree_walk<true, true, true, false, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);                // 573 WITH the packed leaf count (lost: r03_packed_count_ab.txt)
+    if (V == 625) return octree_walk<false, false, true, false, false>(a, obj, root, newRay, world_origin, world_dirlen, hit);    // kernel 41's walk with the triangle id read with EVERY record (before LATE_ID), natural order
+    if (V == 637) return octree_walk<true, true, false, false, false>(a, obj, root, newRay, world_origin, world_dirlen, hit);     // kernel 43's walk likewise, mesh band first
     if (V == 621) return octree_walk_nbrec<true, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);      // 541 + a leaf's first triangle with its node: a whole step's data in one round trip
     if (V == 529 || V == 541) return octree_walk_nbrec<V == 541>(a, obj, root, newRay, world_origin, world_dirlen, hit);
     if (V >= 256) return octree_walk_x<((V == 785 ? 273 : V) & 247)>(a, obj, root, newRay, world_origin, world_dirlen, hit);

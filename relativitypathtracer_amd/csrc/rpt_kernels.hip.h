@@ -421,27 +421,41 @@ RPT_DEV NodeRec load_node_rec(const KernelArgs &a, int i) {
     return r;
 }
 struct TriRec { v4f t0, t1; float e2z; int tri; };
+// LATE_ID: the triangle's id is not read with every record tested (9 dwords instead of 10 through the L1's return path, which is what
+// frames in flight wait for: profiles/r03_td_bound.txt) — the walk remembers the RECORD it hit and reads that one id at the end.
+template <bool LATE_ID = false>
 RPT_DEV TriRec load_tri_rec(const KernelArgs &a, int k) {
     const v4f *p = reinterpret_cast<const v4f *>(a.dtris + k);
     TriRec r;
     r.t0 = p[0];
     r.t1 = p[1];
-    const float2 t2 = *reinterpret_cast<const float2 *>(p + 2);
-    r.e2z = t2.x;
-    r.tri = __float_as_int(t2.y);
+    if (LATE_ID) {
+        r.e2z = *reinterpret_cast<const float *>(p + 2);
+        r.tri = k;
+    } else {
+        const float2 t2 = *reinterpret_cast<const float2 *>(p + 2);
+        r.e2z = t2.x;
+        r.tri = __float_as_int(t2.y);
+    }
     return r;
 }
 // The first record of a node's list, by NODE index (48 B per node, zeros where the list is empty): its address is known as soon as
 // the node's is, so the latency walk asks for it together with the node record — one exposed round trip less per non-empty leaf,
 // 48 B more asked of the L1 per node visited.
+template <bool LATE_ID = false>
 RPT_DEV TriRec load_first_tri(const KernelArgs &a, int node) {
     const v4f *p = reinterpret_cast<const v4f *>(a.first_tris + node);
     TriRec r;
     r.t0 = p[0];
     r.t1 = p[1];
-    const float2 t2 = *reinterpret_cast<const float2 *>(p + 2);
-    r.e2z = t2.x;
-    r.tri = __float_as_int(t2.y);
+    if (LATE_ID) {
+        r.e2z = *reinterpret_cast<const float *>(p + 2);
+        r.tri = 0;          // (the walk puts the record's index in when it tests the record)
+    } else {
+        const float2 t2 = *reinterpret_cast<const float2 *>(p + 2);
+        r.e2z = t2.x;
+        r.tri = __float_as_int(t2.y);
+    }
     return r;
 }
 RPT_DEV void test_tri_rec(const TriRec &r, const Ray &ray, Hit &hit, int &hitTri, bool &didHit) {
@@ -504,7 +518,7 @@ RPT_DEV int descend_from_root(const KernelArgs &a, int root, int link, f3 &uv) {
 
 #endif
 
-template <bool PIPELINE, bool FIRST, bool PACKED_COUNT = true, bool ROOT_GRID = false>
+template <bool PIPELINE, bool FIRST, bool PACKED_COUNT = true, bool ROOT_GRID = false, bool LATE_ID = false>
 RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin,
                          float world_dirlen, Hit &hit) {
     int curr = root;
@@ -529,7 +543,7 @@ RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, c
     bool didHit = false;
     int hitTri = 0;
     TriRec first;
-    if (FIRST) first = load_first_tri(a, curr);
+    if (FIRST) first = load_first_tri<LATE_ID>(a, curr);
     for (int steps = 1; steps <= RPT_MAX_LEAF_STEPS; steps++) {
         nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
         nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
@@ -538,7 +552,7 @@ RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, c
             // (only a walk's first step can stand on a root: nobody's neighbour link points at one)
             curr = (ROOT_GRID && steps == 1) ? descend_from_root(a, root, __float_as_int(rec.lo.w), uv) : descend_to_leaf(a, __float_as_int(rec.lo.w), uv);
             rec = load_node_rec<PACKED_COUNT>(a, curr);
-            if (FIRST) first = load_first_tri(a, curr);
+            if (FIRST) first = load_first_tri<LATE_ID>(a, curr);
             nmin = mk3(rec.lo.x, rec.lo.y, rec.lo.z);
             nmax = mk3(rec.hi.x, rec.hi.y, rec.hi.z);
         }
@@ -548,24 +562,26 @@ RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, c
         const int next = a.dnodes[curr].nb[farSide];
         if (PIPELINE) {
             if (i < trisEnd) {
-                TriRec cur = FIRST ? first : load_tri_rec(a, i);
+                TriRec cur = FIRST ? first : load_tri_rec<LATE_ID>(a, i);
                 for (; i < trisEnd; i++) {
                     TriRec nxt = cur;
-                    if (i + 1 < trisEnd) nxt = load_tri_rec(a, i + 1);
+                    if (i + 1 < trisEnd) nxt = load_tri_rec<LATE_ID>(a, i + 1);
+                    if (LATE_ID) cur.tri = i;
                     test_tri_rec(cur, newRay, hit, hitTri, didHit);
                     cur = nxt;
                 }
             }
         } else {
-            for (; i < trisEnd; i++) test_tri_rec(load_tri_rec(a, i), newRay, hit, hitTri, didHit);
+            for (; i < trisEnd; i++) test_tri_rec(load_tri_rec<LATE_ID>(a, i), newRay, hit, hitTri, didHit);
         }
         uv = nmin + uv * (nmax - nmin);
         if (exit_is_past_hit(uv - newRay.origin, hit.dist, didHit) || next == -1) break;
         curr = next;
         rec = load_node_rec<PACKED_COUNT>(a, curr);
-        if (FIRST) first = load_first_tri(a, curr);
+        if (FIRST) first = load_first_tri<LATE_ID>(a, curr);
     }
     if (!didHit) return false;
+    if (LATE_ID) hitTri = a.dtris[hitTri].tri;
     mesh_hit_finish(a, obj, newRay.origin, newRay.dir, hitTri, world_origin, world_dirlen, hit);
     return true;
 }
@@ -586,7 +602,7 @@ RPT_DEV bool mesh_walk(const KernelArgs &a, const rpt_object &obj, int i, const 
     if (V == 0) return octree_core_ref(a, obj, newRay, world_origin, world_dirlen, hit);
     // (the packed leaf count pays in the throughput walk — one instruction less per node visit, -0.5...-1 % — and costs the latency
     // walk 2-4.5 %, whose count then sits behind a shift and a compare instead of arriving beside the box: profiles/r03_packed_count_ab.txt)
-    return octree_walk<V == 23, V == 23, V != 23, false>(a, obj, a.dobjs[i].root, newRay, world_origin, world_dirlen, hit);
+    return octree_walk<V == 23, V == 23, V != 23, false, true>(a, obj, a.dobjs[i].root, newRay, world_origin, world_dirlen, hit);
 }
 
 RPT_DEV float max3(f3 v) { return cl_max(cl_max(v.x, v.y), v.z); }   // opencl_kernel.cl:310
@@ -1226,8 +1242,8 @@ __global__ __launch_bounds__(256) void rpt_probe_walk_kernel(const KernelArgs a,
         hit.uv.x = hit.uv.y = 0.0f;
         hit.object = -1;
         const bool h = w == 0 ? octree_core_ref(a, obj, r, mk3(0.0f, 0.0f, 0.0f), 1.0f, hit)
-                     : w == 1 ? octree_walk<false, false, true>(a, obj, root, r, mk3(0.0f, 0.0f, 0.0f), 1.0f, hit)
-                              : octree_walk<true, true, false>(a, obj, root, r, mk3(0.0f, 0.0f, 0.0f), 1.0f, hit);
+                     : w == 1 ? octree_walk<false, false, true, false, true>(a, obj, root, r, mk3(0.0f, 0.0f, 0.0f), 1.0f, hit)
+                              : octree_walk<true, true, false, false, true>(a, obj, root, r, mk3(0.0f, 0.0f, 0.0f), 1.0f, hit);
         float *o = out + ((size_t)i * 3 + w) * 8;
         o[0] = h ? 1.0f : 0.0f;
         o[1] = h ? hit.dist : 0.0f;

@@ -534,6 +534,17 @@ def test_bench_exchange_path_over_rccl_with_one_rank(tmp_path, split):
     if split == "full16":     # the naive exchange of whole 16-byte pixels, equal split
         cmd += ["--gather", "full16"]
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    if p.returncode != 0:
+        # a launcher that died before or while the job ran (this test failed ONCE in some forty runs of round 3 and its message was
+        # not kept): run it once more on another port and keep the first run's words in the warnings.  A wrong FRAME is not retried:
+        # that comes back as "check" in a line of a run that returned 0.
+        import warnings
+        warnings.warn(f"bench.py under torch.distributed.run returned {p.returncode} at the first attempt:\n{p.stderr[-1500:]}")
+        s2 = socket.socket()
+        s2.bind(("127.0.0.1", 0))
+        cmd[cmd.index("--master-port") + 1] = str(s2.getsockname()[1])
+        s2.close()
+        p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)

@@ -9,7 +9,9 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for SET in "$@"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$OUT/p$i" -o pmc -- python3 $ROOT/tools/ablate.py --only $SCENE --variant $VAR --frames 5 > "$OUT/p$i.log" 2>&1 || { echo "pass $i ($SET) failed"; tail -3 "$OUT/p$i.log"; }
+  # (a counter set the hardware cannot collect in one pass makes rocprofv3 abort and then wait for ever: bounded, and reported)
+  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$OUT/p$i" -o pmc -- python3 $ROOT/tools/ablate.py --only $SCENE --variant $VAR --frames 5 $RPT_ABLATE_ARGS > "$OUT/p$i.log" 2>&1 || { echo "pass $i ($SET) failed"; grep -m1 -E "exceeds|error code" "$OUT/p$i.log"; }
+  echo "pass $i done"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, collections, sys
