@@ -482,6 +482,8 @@ RPT_DEV bool diag_walk(const KernelArgs &a, const rpt_object &obj, int root, con
     if (V == 589) return octree_walk<true, true, true, false, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);                // 573 WITH the packed leaf count (lost: r03_packed_count_ab.txt)
     if (V == 625) return octree_walk<false, false, true, false, false>(a, obj, root, newRay, world_origin, world_dirlen, hit);    // kernel 41's walk with the triangle id read with EVERY record (before LATE_ID), natural order
     if (V == 637) return octree_walk<true, true, false, false, false>(a, obj, root, newRay, world_origin, world_dirlen, hit);     // kernel 43's walk likewise, mesh band first
+    if (V == 641) return octree_walk<false, false, true, false, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);     // kernel 41's walk; the LANES of the wave follow the Z curve (render_pixel_body)
+    if (V == 653) return octree_walk<true, true, false, false, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);      // kernel 43's walk, likewise, mesh band first
     if (V == 621) return octree_walk_nbrec<true, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);      // 541 + a leaf's first triangle with its node: a whole step's data in one round trip
     if (V == 529 || V == 541) return octree_walk_nbrec<V == 541>(a, obj, root, newRay, world_origin, world_dirlen, hit);
     if (V >= 256) return octree_walk_x<((V == 785 ? 273 : V) & 247)>(a, obj, root, newRay, world_origin, world_dirlen, hit);

@@ -951,6 +951,7 @@ RPT_DEV unsigned long long wave_object_mask(const KernelArgs &a, int tile_x0, in
 }
 
 template <int V> RPT_DEV constexpr bool culled_variant() { return V >= 20; }
+template <int V> RPT_DEV constexpr bool zorder_lanes() { return V == 641 || V == 653; }
 template <int V> RPT_DEV constexpr bool band_first_variant() { return V == 23 || V == 123 || (V >= 256 && V < 1000 && (V & 8)); }
 
 // ---------------------------------------------------------------------------------------------
@@ -977,8 +978,16 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
         const int y = (int)blockIdx.y, rh = a.first_h;
         tile_row = y < rh ? a.first_ty + y : (y - rh < a.first_ty ? y - rh : y);
     }
+    // lane -> pixel of the wave's 8x8 tile: row by row.  Diagnostics library, arms 641 / 653: along the Z curve, so that the four lanes the
+    // memory pipeline handles together are a 2x2 block of pixels, not a 4x1 run (level, +1 % in flight at 4K and 8K: r03_td_bound.txt)
+#ifdef RPT_DIAGNOSTICS
+    const int col_in_tile = zorder_lanes<V>() ? ((lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4)) : (lane & 7);
+    const int row_in_tile = zorder_lanes<V>() ? (((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4)) : (lane >> 3);
+    const int x_coord = strip * 32 + wave * 8 + col_in_tile;
+#else
     const int row_in_tile = lane >> 3;
     const int x_coord = strip * 32 + wave * 8 + (lane & 7);
+#endif
     const int local_row = tile_row * RPT_TILE_ROWS + row_in_tile;
     const int global_tile = (tile_row >> a.run_log2) * a.tile_step + a.first_tile + (tile_row & ((1 << a.run_log2) - 1));
     const int y_coord = global_tile * RPT_TILE_ROWS + row_in_tile;
