@@ -522,18 +522,47 @@ RPT_DEV int descend_from_root(const KernelArgs &a, int root, int link, f3 &uv) {
 // 74 %: profiles/r02_divergence.txt) the node record and the leaf's triangle records are read ONCE for the wave — the address is made
 // wave-uniform with readfirstlane, so the loads go through the scalar cache into SGPRs instead of 64 times through the vector L1's
 // return path — and the arithmetic takes them as scalar operands.  Same operations on the same values.
-template <bool PACKED_COUNT, bool UNIFORM>
+// UNIFORM = 1: through the scalar cache (above).  UNIFORM = 2: ONE lane of the wave makes the vector loads (an L1 hit as before, one
+// lane's worth of work for the return path instead of the wave's) and readfirstlane hands the dwords to everybody as scalars.
+RPT_DEV float bcast_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+RPT_DEV v4f bcast_v4(v4f v) { v4f r; r.x = bcast_f(v.x); r.y = bcast_f(v.y); r.z = bcast_f(v.z); r.w = bcast_f(v.w); return r; }
+template <bool PACKED_COUNT, int UNIFORM>
 RPT_DEV NodeRec load_node_rec_u(const KernelArgs &a, int curr, bool &uni) {
     uni = false;
     if (UNIFORM) {
         const int u = __builtin_amdgcn_readfirstlane(curr);
         uni = __ballot(curr != u) == 0ull;
-        if (uni) return load_node_rec<PACKED_COUNT>(a, u);
+        if (uni && UNIFORM == 1) return load_node_rec<PACKED_COUNT>(a, u);
+        if (uni) {
+            const bool leader = (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1;
+            NodeRec r;
+            r.lo = r.hi = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+            r.count = 0;
+            if (leader) r = load_node_rec<PACKED_COUNT>(a, curr);
+            r.lo = bcast_v4(r.lo);
+            r.hi = bcast_v4(r.hi);
+            r.count = __builtin_amdgcn_readfirstlane(r.count);
+            return r;
+        }
     }
     return load_node_rec<PACKED_COUNT>(a, curr);
 }
+template <bool LATE_ID>
+RPT_DEV TriRec load_tri_rec_leader(const KernelArgs &a, int k) {
+    const bool leader = (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1;
+    TriRec r;
+    r.t0 = r.t1 = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    r.e2z = 0.0f;
+    r.tri = 0;
+    if (leader) r = load_tri_rec<LATE_ID>(a, k);
+    r.t0 = bcast_v4(r.t0);
+    r.t1 = bcast_v4(r.t1);
+    r.e2z = bcast_f(r.e2z);
+    r.tri = __builtin_amdgcn_readfirstlane(r.tri);
+    return r;
+}
 
-template <bool PIPELINE, bool FIRST, bool PACKED_COUNT = true, bool ROOT_GRID = false, bool LATE_ID = false, bool UNIFORM = false>
+template <bool PIPELINE, bool FIRST, bool PACKED_COUNT = true, bool ROOT_GRID = false, bool LATE_ID = false, int UNIFORM = 0>
 RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin,
                          float world_dirlen, Hit &hit) {
     int curr = root;
@@ -578,7 +607,8 @@ RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, c
         const int next = a.dnodes[curr].nb[farSide];
         if (UNIFORM && uni) {          // one list for the whole wave: records through the scalar cache
             const int ue = __builtin_amdgcn_readfirstlane(trisEnd);
-            for (int k = __builtin_amdgcn_readfirstlane(i); k < ue; k++) test_tri_rec(load_tri_rec<LATE_ID>(a, k), newRay, hit, hitTri, didHit);
+            for (int k = __builtin_amdgcn_readfirstlane(i); k < ue; k++)
+                test_tri_rec(UNIFORM == 2 ? load_tri_rec_leader<LATE_ID>(a, k) : load_tri_rec<LATE_ID>(a, k), newRay, hit, hitTri, didHit);
         } else if (PIPELINE) {
             if (i < trisEnd) {
                 TriRec cur = FIRST ? first : load_tri_rec<LATE_ID>(a, i);
