@@ -518,7 +518,14 @@ RPT_DEV int descend_from_root(const KernelArgs &a, int root, int link, f3 &uv) {
 
 #endif
 
-// UNIFORM (experiment): where every active lane of the wave stands in the SAME node (bunny 4K: 42 % of the wave's leaf steps, shadows
+// MEASUREMENT ARMS (UNIFORM = 1 / 2; diagnostics library, arms 657 / 669 / 673; bit-identical, 3-16 % slower: profiles/r03_td_bound.txt).
+#ifndef RPT_DIAGNOSTICS
+template <bool PACKED_COUNT, int UNIFORM>
+RPT_DEV NodeRec load_node_rec_u(const KernelArgs &a, int curr, bool &uni) { uni = false; return load_node_rec<PACKED_COUNT>(a, curr); }
+template <bool LATE_ID>
+RPT_DEV TriRec load_tri_rec_leader(const KernelArgs &a, int k) { return load_tri_rec<LATE_ID>(a, k); }
+#else
+// UNIFORM = 1: where every active lane of the wave stands in the SAME node (bunny 4K: 42 % of the wave's leaf steps, shadows
 // 74 %: profiles/r02_divergence.txt) the node record and the leaf's triangle records are read ONCE for the wave — the address is made
 // wave-uniform with readfirstlane, so the loads go through the scalar cache into SGPRs instead of 64 times through the vector L1's
 // return path — and the arithmetic takes them as scalar operands.  Same operations on the same values.
@@ -561,6 +568,8 @@ RPT_DEV TriRec load_tri_rec_leader(const KernelArgs &a, int k) {
     r.tri = __builtin_amdgcn_readfirstlane(r.tri);
     return r;
 }
+
+#endif
 
 template <bool PIPELINE, bool FIRST, bool PACKED_COUNT = true, bool ROOT_GRID = false, bool LATE_ID = false, int UNIFORM = 0>
 RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin,
