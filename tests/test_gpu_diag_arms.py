@@ -10,6 +10,12 @@ renders something else would be worthless.  So they are held to the product's ba
               from global memory / the persistent skeleton around the per-pixel trace
   61        the per-workgroup LDS ray queue
   256+f     the product walk with its round trips re-ordered further (flags: rpt_diag_walks.hip.h)
+  529, 541, 621   the six neighbour indices read with the node record (/ + records ahead / + the first triangle too: a step in one round trip)
+  561, 573  = kernel 43's latency walk, natural order / mesh band first;  2573 the same at four waves per SIMD
+  589       the latency walk with the packed leaf count;  625, 637 kernel 41's / 43's walk with the triangle id read with every record
+  593, 605  the 16^3 root table (descend_from_root) in kernel 41's / 43's walk
+  641, 653  the lanes of a wave along the Z curve through its tile
+  657, 669, 673   records read once per wave where the wave stands in one node: through the scalar cache / by one lane + readfirstlane
 """
 import numpy as np
 import pytest
