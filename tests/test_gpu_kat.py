@@ -220,6 +220,11 @@ def test_octree_walk_at_ray_level(scene_name):
     r = Renderer(0)
     r.upload_scene(scene)
     got = r.probe_walk(mesh, rays)
+    from relativitypathtracer_amd.renderer import RenderError
+    not_a_mesh = int(np.flatnonzero(np.asarray(objs["type"]) != 2)[0])
+    for bad in (not_a_mesh, -1, len(objs)):
+        with pytest.raises(RenderError):
+            r.probe_walk(bad, rays[:4])
     r.close()
     hits = int(want[:, 0].sum())
     assert 0.15 * n < hits < 0.9 * n, hits               # the sample exercises hits and misses
