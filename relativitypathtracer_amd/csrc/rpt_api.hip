@@ -572,14 +572,14 @@ int launch_diagnostic(rpt_ctx *ctx, rptd::KernelArgs &a, dim3 grid, int tiles, i
         hipLaunchKernelGGL(rptd::rpt_render_kernel_v1_masked_w5, grid, dim3(256), 0, ctx->stream, a);
         break;
     }
-    case 40: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w4, grid, dim3(256), 0, ctx->stream, a); break;
-    case 42: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w6, grid, dim3(256), 0, ctx->stream, a); break;
+    case 40: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w4, dim3(grid.x * 4, grid.y), dim3(64), 0, ctx->stream, a); break;      // (kernel 41's body: one wave per workgroup)
+    case 42: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w6, dim3(grid.x * 4, grid.y), dim3(64), 0, ctx->stream, a); break;
     case 141: hipLaunchKernelGGL(rptd::rpt_render_kernel_r02walk_w5, grid, dim3(256), 0, ctx->stream, a); break;
     case 143: hipLaunchKernelGGL(rptd::rpt_render_kernel_r02walk_first_w5, grid, dim3(256), 0, ctx->stream, a); break;
     case 60: case 62: case 63: {
         const int rc = launch_persistent(ctx, a, tiles, v);
         if (rc > 0) return rc;
-        if (rc < 0) hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w5, grid, dim3(256), 0, ctx->stream, a);     // (tiny or enormous frames)
+        if (rc < 0) hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w5, dim3(grid.x * 4, grid.y), dim3(64), 0, ctx->stream, a);     // (tiny or enormous frames: the product kernel)
         break;
     }
     case 61: hipLaunchKernelGGL(rptd::rpt_render_kernel_queue_w5, grid, dim3(256), 0, ctx->stream, a); break;
@@ -589,6 +589,7 @@ int launch_diagnostic(rpt_ctx *ctx, rptd::KernelArgs &a, dim3 grid, int tiles, i
     case 2257: hipLaunchKernelGGL(rptd::rpt_render_kernel_x257_w4, grid, dim3(256), 0, ctx->stream, a); break;
     case 2259: hipLaunchKernelGGL(rptd::rpt_render_kernel_x259_w4, grid, dim3(256), 0, ctx->stream, a); break;
     case 2263: hipLaunchKernelGGL(rptd::rpt_render_kernel_x263_w4, grid, dim3(256), 0, ctx->stream, a); break;
+    RPT_LAUNCH_X(689) RPT_LAUNCH_X(701)          // kernel 41's / 43's walk launched four waves per workgroup (what the product did before)
     case 2573: hipLaunchKernelGGL(rptd::rpt_render_kernel_x573_w4, grid, dim3(256), 0, ctx->stream, a); break;      // the latency kernel at 4 waves per SIMD (128 VGPRs, no scratch)
     case 7:
         if (int rc = reserve(ctx, ctx->counters, 16 * sizeof(unsigned long long))) return rc;
@@ -620,10 +621,8 @@ int launch(rpt_ctx *ctx) {
     a.dtris = (const rptd::DTri *)ctx->geo->dtris.ptr;
     a.links = (const int *)ctx->geo->dlinks.ptr;
     a.first_tris = (const rptd::DTri *)ctx->geo->dfirst.ptr;
-#ifdef RPT_DIAGNOSTICS
-    a.root_grids = (const int *)ctx->geo->dgrids.ptr;
+    a.root_grids = (const int *)ctx->geo->dgrids.ptr;       // (null and 0 in the product library)
     a.grid_roots = ctx->geo->grid_roots;
-#endif
     a.top_count = ctx->geo->top_count;
     a.dobjs = (const rptd::DObj *)((const char *)ctx->objects.ptr + (size_t)ctx->object_count * sizeof(rpt_object));
     a.objects = (const rpt_object *)ctx->objects.ptr;
@@ -668,7 +667,8 @@ int launch(rpt_ctx *ctx) {
 
     const int tiles = local_tile_count(ctx);
     if (tiles == 0) return RPT_OK;
-    const dim3 grid((ctx->width + 31) / 32, tiles);
+    const dim3 grid((ctx->width + 31) / 32, tiles);         // the measurement arms: four waves (a 32 x 8 strip) per workgroup
+    const dim3 grid1(((ctx->width + 31) / 32) * 4, tiles);  // the product kernels: one wave (an 8 x 8 tile) per workgroup
     // variant 0 = default.  rpt_render_async() is a throughput call (frames in flight fill each other's gaps): the in-wave
     // cull kernel in natural order (41).  The blocking rpt_render() is a latency call — its caller waits for this frame, and the
     // frame is as long as its longest wave — so the band of tile rows that holds the meshes is dispatched first and the walk asks
@@ -696,16 +696,16 @@ int launch(rpt_ctx *ctx) {
         v = v == 3 ? 47 : 46;
     }
     switch (v) {
-    case 46: hipLaunchKernelGGL(rptd::rpt_render_kernel_msaa_w5, grid, dim3(256), 0, ctx->stream, a); break;
-    case 47: hipLaunchKernelGGL(rptd::rpt_render_kernel_msaa_unculled_w5, grid, dim3(256), 0, ctx->stream, a); break;
-    case 1: hipLaunchKernelGGL(rptd::rpt_render_kernel_v0, grid, dim3(256), 0, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL(rptd::rpt_render_kernel_unculled_w5, grid, dim3(256), 0, ctx->stream, a); break;
-    case 41: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w5, grid, dim3(256), 0, ctx->stream, a); break;
-    case 43: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_first_w5, grid, dim3(256), 0, ctx->stream, a); break;
-    case 44: hipLaunchKernelGGL(rptd::rpt_render_kernel_analytic_w8, grid, dim3(256), 0, ctx->stream, a); break;
+    case 46: hipLaunchKernelGGL(rptd::rpt_render_kernel_msaa_w5, grid1, dim3(64), 0, ctx->stream, a); break;
+    case 47: hipLaunchKernelGGL(rptd::rpt_render_kernel_msaa_unculled_w5, grid1, dim3(64), 0, ctx->stream, a); break;
+    case 1: hipLaunchKernelGGL(rptd::rpt_render_kernel_v0, grid1, dim3(64), 0, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL(rptd::rpt_render_kernel_unculled_w5, grid1, dim3(64), 0, ctx->stream, a); break;
+    case 41: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_w5, grid1, dim3(64), 0, ctx->stream, a); break;
+    case 43: hipLaunchKernelGGL(rptd::rpt_render_kernel_ballot_first_w5, grid1, dim3(64), 0, ctx->stream, a); break;
+    case 44: hipLaunchKernelGGL(rptd::rpt_render_kernel_analytic_w8, grid1, dim3(64), 0, ctx->stream, a); break;
     case 50:
     case 51:
-        if (rpt_launch_relaxed_kernel(v == 51 ? 6 : 5, &a, sizeof a, grid.x, grid.y, (void *)ctx->stream)) return fail(ctx, RPT_ERR_DEVICE, "relaxed-arithmetic kernel launch failed");
+        if (rpt_launch_relaxed_kernel(v == 51 ? 6 : 5, &a, sizeof a, grid1.x, grid1.y, (void *)ctx->stream)) return fail(ctx, RPT_ERR_DEVICE, "relaxed-arithmetic kernel launch failed");
         break;
     default:
 #ifdef RPT_DIAGNOSTICS
@@ -1319,10 +1319,8 @@ int rpt_probe_walk(rpt_ctx *ctx, int object_index, const float *host_rays, float
     a.dtris = (const rptd::DTri *)ctx->geo->dtris.ptr;
     a.links = (const int *)ctx->geo->dlinks.ptr;
     a.first_tris = (const rptd::DTri *)ctx->geo->dfirst.ptr;
-#ifdef RPT_DIAGNOSTICS
-    a.root_grids = (const int *)ctx->geo->dgrids.ptr;
+    a.root_grids = (const int *)ctx->geo->dgrids.ptr;       // (null and 0 in the product library)
     a.grid_roots = ctx->geo->grid_roots;
-#endif
     a.top_count = ctx->geo->top_count;
     a.dobjs = (const rptd::DObj *)((const char *)ctx->objects.ptr + (size_t)ctx->object_count * sizeof(rpt_object));
     a.objects = (const rpt_object *)ctx->objects.ptr;

@@ -2,9 +2,9 @@
 //
 // What is computed is the reference's render_kernel (opencl_kernel.cl:620-660) and everything it
 // calls; how it is computed is organised for MI355X:
-//   * one wavefront owns an 8x8 pixel tile (coherent rays, 8 full 128-B lines per store wave),
-//     a 256-thread workgroup owns a 32x8 strip; the grid is (ceil(W/32), row tiles) so it is
-//     >> 256 workgroups at every benchmark resolution;
+//   * one wavefront owns an 8x8 pixel tile (coherent rays, 8 full 128-B lines per store wave) and is a workgroup
+//     of its own (its slot is free again when IT ends, not when the longest of four neighbours does); the grid is
+//     (4 ceil(W/32), row tiles): 129 600 workgroups at 4K.  The measurement arms keep four waves per workgroup;
 //   * Object[] is indexed with a wave-uniform loop counter, so the matrices arrive through the
 //     scalar cache into SGPRs (s_load) and are broadcast for free; per-frame constants that do
 //     not depend on the pixel (aspect ratio, hable(white_point)) are computed once on the host
@@ -103,10 +103,8 @@ struct KernelArgs {
     const DObj *dobjs;
     const int *links;               // DNode::link of every node again, 4 B apart: what a descent reads per level
     const DTri *first_tris;         // per node: the first triangle record of its leaf list again, addressable by the NODE's index
-#ifdef RPT_DIAGNOSTICS
-    const int *root_grids;          // per octree root (the first grid_roots derived nodes): 16^3 cells -> node | level << 24 | leaf << 28 (arms 593 / 605)
+    const int *root_grids;          // (diagnostics library: arms 593 / 605) per octree root, 16^3 cells -> node | level << 24 | leaf << 28; product: null
     int grid_roots;
-#endif
     int top_count;                  // nodes [0, top_count) are the forest's top levels (whole levels, <= RPT_TOP_MAX)
     // persistent kernels (rpt_persistent.hip.h): the band of tile rows that holds the meshes (first_ty, first_h above) is
     // claimed tile by tile from per-queue counters, the other rows are dealt statically in runs of RPT_SKY_RUN tiles
@@ -1010,6 +1008,7 @@ RPT_DEV unsigned long long wave_object_mask(const KernelArgs &a, int tile_x0, in
 
 template <int V> RPT_DEV constexpr bool culled_variant() { return V >= 20; }
 template <int V> RPT_DEV constexpr bool zorder_lanes() { return V == 641 || V == 653; }
+template <int V> RPT_DEV constexpr bool one_wave_workgroups() { return V == 0 || V == 1 || V == 20 || V == 23 || V == 24; }     // the product kernels
 template <int V> RPT_DEV constexpr bool band_first_variant() { return V == 23 || V == 123 || (V >= 256 && V < 1000 && (V & 8)); }
 
 // ---------------------------------------------------------------------------------------------
@@ -1023,12 +1022,15 @@ template <int V> RPT_DEV constexpr bool band_first_variant() { return V == 23 ||
 template <int V>
 RPT_DEV void render_pixel_body(const KernelArgs &a) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // The product kernels are launched ONE WAVE per workgroup (blockDim 64, grid.x = tiles per row): a wave slot is handed back when
+    // its wave ends, not when the longest of four neighbours does — next to a tile that walks for 70 us sit tiles that only store
+    // (profiles/r03_one_wave_workgroups_ab.txt: bunny 4K in flight -8 %, one at a time -3 %).  The measurement arms keep 4 x 64.
+    const int wave = one_wave_workgroups<V>() ? ((int)blockIdx.x & 3) : (int)(threadIdx.x >> 6);
+    const int strip = one_wave_workgroups<V>() ? ((int)blockIdx.x >> 2) : (int)blockIdx.x;      // 32-pixel-wide strip of that row
 #ifdef RPT_DIAGNOSTICS
     const DiagWaveClock diag_clock0 = diag_wave_begin<V>();
 #endif
     int tile_row = (int)blockIdx.y;              // 8-row tiles of this context, natural order
-    const int strip = (int)blockIdx.x;           // 32-pixel-wide strip of that row
     if (band_first_variant<V>() && a.first_h > 0) {
         // Workgroups are handed out in the order of their linear index, i.e. row of strips by row of strips.  One frame at a
         // time, what ends the frame is the last of its long waves, so the band of tile rows that holds the meshes goes first
@@ -1097,9 +1099,9 @@ RPT_DEV void render_pixel_body(const KernelArgs &a) {
 template <int V>
 RPT_DEV void render_pixel_body_msaa(const KernelArgs &a) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = (int)blockIdx.x & 3;              // one wave per workgroup, as the one-sample product kernels
     const int tile_row = (int)blockIdx.y;
-    const int strip = (int)blockIdx.x;
+    const int strip = (int)blockIdx.x >> 2;
     const int row_in_tile = lane >> 3;
     const int x_coord = strip * 32 + wave * 8 + (lane & 7);
     const int local_row = tile_row * RPT_TILE_ROWS + row_in_tile;
@@ -1138,19 +1140,19 @@ RPT_DEV void render_pixel_body_msaa(const KernelArgs &a) {
 
 #ifndef RPT_RELAXED_FP    /* rpt_relaxed.hip instantiates its own two kernels and nothing else from here on */
 // Product kernels (rpt_set_variant; the number in the comment is the variant).
-__global__ __launch_bounds__(256) void rpt_render_kernel_v0(const KernelArgs a) { render_pixel_body<0>(a); }                                                              // 1: any valid octree
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_unculled_w5(const KernelArgs a) { render_pixel_body<1>(a); }         // 3: no cull (rpt_verify_frame; the escape hatch)
+__global__ __launch_bounds__(64) void rpt_render_kernel_v0(const KernelArgs a) { render_pixel_body<0>(a); }                                                              // 1: any valid octree
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_unculled_w5(const KernelArgs a) { render_pixel_body<1>(a); }         // 3: no cull (rpt_verify_frame; the escape hatch)
 // the wave's object mask from the per-object screen rectangles by lane-parallel test + __ballot, 5 waves per SIMD (96 VGPRs, 8 B of scratch outside the loops)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_w5(const KernelArgs a) { render_pixel_body<20>(a); }          // 41 = rpt_render_async
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_w5(const KernelArgs a) { render_pixel_body<20>(a); }          // 41 = rpt_render_async
 // the same with the tile rows that hold the meshes dispatched first and the latency walk (44 B of scratch): latency, not throughput
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_first_w5(const KernelArgs a) { render_pixel_body<23>(a); }    // 43 = the blocking rpt_render; rpt_render_async below RPT_LATENCY_KERNEL_MAX_PIXELS
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_ballot_first_w5(const KernelArgs a) { render_pixel_body<23>(a); }    // 43 = the blocking rpt_render; rpt_render_async below RPT_LATENCY_KERNEL_MAX_PIXELS
 // without the octree walk compiled in, for frames whose Object[] holds no mesh: 61 VGPRs, no scratch, EIGHT waves per SIMD
 // (arch 1080p 0.0370 -> 0.0301 ms per frame in flight, cubes.txt 4K 0.0898 -> 0.0725)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_analytic_w8(const KernelArgs a) { render_pixel_body<24>(a); }        // 44
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void rpt_render_kernel_analytic_w8(const KernelArgs a) { render_pixel_body<24>(a); }        // 44
 
 // MSAASAMPLES > 1 (rpt_set_msaa): culled and un-culled; rpt_last_variant reports them as 46 / 47
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_msaa_w5(const KernelArgs a) { render_pixel_body_msaa<20>(a); }            // 46
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_msaa_unculled_w5(const KernelArgs a) { render_pixel_body_msaa<1>(a); }    // 47
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_msaa_w5(const KernelArgs a) { render_pixel_body_msaa<20>(a); }            // 46
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_msaa_unculled_w5(const KernelArgs a) { render_pixel_body_msaa<1>(a); }    // 47
 
 #ifdef RPT_DIAGNOSTICS
 }  // namespace rptd

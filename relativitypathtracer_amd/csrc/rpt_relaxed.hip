@@ -16,8 +16,8 @@
 #include "rpt_kernels.hip.h"
 
 namespace rptd_relaxed {
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_relaxed_w5(const KernelArgs a) { render_pixel_body<20>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_relaxed_w6(const KernelArgs a) { render_pixel_body<20>(a); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_relaxed_w5(const KernelArgs a) { render_pixel_body<20>(a); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void rpt_render_kernel_relaxed_w6(const KernelArgs a) { render_pixel_body<20>(a); }
 }  // namespace rptd_relaxed
 
 // args: the exact build's rptd::KernelArgs, byte for byte (same struct definition, other namespace)
@@ -25,7 +25,7 @@ extern "C" int rpt_launch_relaxed_kernel(int waves_per_simd, const void *args, s
     if (!args || args_bytes != sizeof(rptd_relaxed::KernelArgs)) return 1;
     rptd_relaxed::KernelArgs a;
     __builtin_memcpy(&a, args, sizeof a);
-    if (waves_per_simd == 6) hipLaunchKernelGGL(rptd_relaxed::rpt_render_kernel_relaxed_w6, dim3(grid_x, grid_y), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(rptd_relaxed::rpt_render_kernel_relaxed_w5, dim3(grid_x, grid_y), dim3(256), 0, (hipStream_t)stream, a);
+    if (waves_per_simd == 6) hipLaunchKernelGGL(rptd_relaxed::rpt_render_kernel_relaxed_w6, dim3(grid_x, grid_y), dim3(64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(rptd_relaxed::rpt_render_kernel_relaxed_w5, dim3(grid_x, grid_y), dim3(64), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

@@ -25,7 +25,7 @@ from conftest import load_config
 
 pytestmark = pytest.mark.gpu
 
-ARMS = [26, 40, 42, 141, 143, 60, 61, 62, 63, 256, 257, 259, 261, 263, 265, 269, 273, 277, 285, 305, 317, 337, 349, 401, 1257, 2257, 2259, 2263, 529, 541, 561, 573, 589, 593, 605, 621, 625, 637, 641, 653, 657, 669, 673, 2573]
+ARMS = [26, 40, 42, 141, 143, 60, 61, 62, 63, 256, 257, 259, 261, 263, 265, 269, 273, 277, 285, 305, 317, 337, 349, 401, 1257, 2257, 2259, 2263, 529, 541, 561, 573, 589, 593, 605, 621, 625, 637, 641, 653, 657, 669, 673, 689, 701, 2573]
 SCENES = {"bunny": (480, 270), "shadows": (480, 270), "arch": (480, 270), "cubes": (320, 184), "soccer": (320, 184), "cube": (333, 77)}
 
 
