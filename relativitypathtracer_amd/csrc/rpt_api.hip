@@ -584,11 +584,14 @@ int launch_diagnostic(rpt_ctx *ctx, rptd::KernelArgs &a, dim3 grid, int tiles, i
     }
     case 61: hipLaunchKernelGGL(rptd::rpt_render_kernel_queue_w5, grid, dim3(256), 0, ctx->stream, a); break;
     RPT_LAUNCH_X(256) RPT_LAUNCH_X(257) RPT_LAUNCH_X(259) RPT_LAUNCH_X(261) RPT_LAUNCH_X(263) RPT_LAUNCH_X(265) RPT_LAUNCH_X(269)
-    RPT_LAUNCH_X(273) RPT_LAUNCH_X(277) RPT_LAUNCH_X(285) RPT_LAUNCH_X(305) RPT_LAUNCH_X(317) RPT_LAUNCH_X(337) RPT_LAUNCH_X(349) RPT_LAUNCH_X(401) RPT_LAUNCH_X(785) RPT_LAUNCH_X(529) RPT_LAUNCH_X(541) RPT_LAUNCH_X(561) RPT_LAUNCH_X(573) RPT_LAUNCH_X(589) RPT_LAUNCH_X(605) RPT_LAUNCH_X(621) RPT_LAUNCH_X(625) RPT_LAUNCH_X(637) RPT_LAUNCH_X(641) RPT_LAUNCH_X(653) RPT_LAUNCH_X(657) RPT_LAUNCH_X(669) RPT_LAUNCH_X(673) RPT_LAUNCH_X(593)
+    RPT_LAUNCH_X(273) RPT_LAUNCH_X(277) RPT_LAUNCH_X(285) RPT_LAUNCH_X(305) RPT_LAUNCH_X(317) RPT_LAUNCH_X(337) RPT_LAUNCH_X(349) RPT_LAUNCH_X(401) RPT_LAUNCH_X(785) RPT_LAUNCH_X(529) RPT_LAUNCH_X(541) RPT_LAUNCH_X(561) RPT_LAUNCH_X(573) RPT_LAUNCH_X(589) RPT_LAUNCH_X(605) RPT_LAUNCH_X(621) RPT_LAUNCH_X(625) RPT_LAUNCH_X(637) RPT_LAUNCH_X(641) RPT_LAUNCH_X(653) RPT_LAUNCH_X(593)
     case 1257: hipLaunchKernelGGL(rptd::rpt_render_kernel_x257_w6, grid, dim3(256), 0, ctx->stream, a); break;
     case 2257: hipLaunchKernelGGL(rptd::rpt_render_kernel_x257_w4, grid, dim3(256), 0, ctx->stream, a); break;
     case 2259: hipLaunchKernelGGL(rptd::rpt_render_kernel_x259_w4, grid, dim3(256), 0, ctx->stream, a); break;
     case 2263: hipLaunchKernelGGL(rptd::rpt_render_kernel_x263_w4, grid, dim3(256), 0, ctx->stream, a); break;
+    case 657: hipLaunchKernelGGL(rptd::rpt_render_kernel_x657, dim3(grid.x * 4, grid.y), dim3(64), 0, ctx->stream, a); break;
+    case 669: hipLaunchKernelGGL(rptd::rpt_render_kernel_x669, dim3(grid.x * 4, grid.y), dim3(64), 0, ctx->stream, a); break;
+    case 673: hipLaunchKernelGGL(rptd::rpt_render_kernel_x673, dim3(grid.x * 4, grid.y), dim3(64), 0, ctx->stream, a); break;
     RPT_LAUNCH_X(689) RPT_LAUNCH_X(701)          // kernel 41's / 43's walk launched four waves per workgroup (what the product did before)
     case 2573: hipLaunchKernelGGL(rptd::rpt_render_kernel_x573_w4, grid, dim3(256), 0, ctx->stream, a); break;      // the latency kernel at 4 waves per SIMD (128 VGPRs, no scratch)
     case 7:

@@ -93,10 +93,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_r02walk_w5(const KernelArgs a) { render_pixel_body<120>(a); }      // 141: round 2's walk, natural order
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_r02walk_first_w5(const KernelArgs a) { render_pixel_body<123>(a); } // 143: round 2's walk, mesh band first
 #define RPT_X_KERNEL(N) __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_x##N(const KernelArgs a) { render_pixel_body<N>(a); }
+#define RPT_X1_KERNEL(N) __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_x##N(const KernelArgs a) { render_pixel_body<N>(a); }
+RPT_X1_KERNEL(657) RPT_X1_KERNEL(669) RPT_X1_KERNEL(673)      /* one wave per workgroup, like the product kernels they are compared with */
 #define RPT_XW_KERNEL(N, W) __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) void rpt_render_kernel_x##N##_w##W(const KernelArgs a) { render_pixel_body<N>(a); }
 RPT_XW_KERNEL(257, 6) RPT_XW_KERNEL(257, 4) RPT_XW_KERNEL(263, 4) RPT_XW_KERNEL(259, 4) RPT_XW_KERNEL(573, 4)
 RPT_X_KERNEL(256) RPT_X_KERNEL(257) RPT_X_KERNEL(259) RPT_X_KERNEL(261) RPT_X_KERNEL(263) RPT_X_KERNEL(265) RPT_X_KERNEL(269)
-RPT_X_KERNEL(273) RPT_X_KERNEL(277) RPT_X_KERNEL(285) RPT_X_KERNEL(305) RPT_X_KERNEL(317) RPT_X_KERNEL(337) RPT_X_KERNEL(349) RPT_X_KERNEL(401) RPT_X_KERNEL(785) RPT_X_KERNEL(529) RPT_X_KERNEL(541) RPT_X_KERNEL(561) RPT_X_KERNEL(573) RPT_X_KERNEL(589) RPT_X_KERNEL(605) RPT_X_KERNEL(621) RPT_X_KERNEL(625) RPT_X_KERNEL(637) RPT_X_KERNEL(641) RPT_X_KERNEL(653) RPT_X_KERNEL(657) RPT_X_KERNEL(669) RPT_X_KERNEL(673) RPT_X_KERNEL(689) RPT_X_KERNEL(701) RPT_X_KERNEL(593)
+RPT_X_KERNEL(273) RPT_X_KERNEL(277) RPT_X_KERNEL(285) RPT_X_KERNEL(305) RPT_X_KERNEL(317) RPT_X_KERNEL(337) RPT_X_KERNEL(349) RPT_X_KERNEL(401) RPT_X_KERNEL(785) RPT_X_KERNEL(529) RPT_X_KERNEL(541) RPT_X_KERNEL(561) RPT_X_KERNEL(573) RPT_X_KERNEL(589) RPT_X_KERNEL(605) RPT_X_KERNEL(621) RPT_X_KERNEL(625) RPT_X_KERNEL(637) RPT_X_KERNEL(641) RPT_X_KERNEL(653) RPT_X_KERNEL(689) RPT_X_KERNEL(701) RPT_X_KERNEL(593)
 
 }  // namespace rptd
 

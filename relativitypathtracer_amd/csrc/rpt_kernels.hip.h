@@ -1008,7 +1008,7 @@ RPT_DEV unsigned long long wave_object_mask(const KernelArgs &a, int tile_x0, in
 
 template <int V> RPT_DEV constexpr bool culled_variant() { return V >= 20; }
 template <int V> RPT_DEV constexpr bool zorder_lanes() { return V == 641 || V == 653; }
-template <int V> RPT_DEV constexpr bool one_wave_workgroups() { return V == 0 || V == 1 || V == 20 || V == 23 || V == 24; }     // the product kernels
+template <int V> RPT_DEV constexpr bool one_wave_workgroups() { return V == 0 || V == 1 || V == 20 || V == 23 || V == 24 || V == 657 || V == 669 || V == 673; }     // the product kernels (+ three arms re-measured that way)
 template <int V> RPT_DEV constexpr bool band_first_variant() { return V == 23 || V == 123 || (V >= 256 && V < 1000 && (V & 8)); }
 
 // ---------------------------------------------------------------------------------------------
