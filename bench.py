@@ -169,14 +169,12 @@ def launch_ranks(n):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as CHILD processes through
     torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and pass rank 0's output through.  Nothing in
     this process has touched the GPU or imported torch.cuda state at this point, and nothing is exec'd."""
-    import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # The rendezvous belongs to the launcher: its c10d store binds port 0 itself and hands MASTER_ADDR / MASTER_PORT to the ranks.
+    # (Rounds 1-3 picked a port here by bind / close / pass-the-number: between the close and the launcher's own bind any other
+    # process of the box may take it, and the job dies at start-up — DESIGN.md 8, item 2.)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--rdzv-backend=c10d",
+           "--rdzv-endpoint=127.0.0.1:0", "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, RPT_BENCH_CHILD="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode

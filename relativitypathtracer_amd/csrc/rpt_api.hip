@@ -1038,11 +1038,13 @@ int rpt_verify_frame(rpt_ctx *ctx, unsigned long long *differing_pixels) {
     int rc = RPT_OK;
     ctx->external_plane = plane_a;
     rc = launch(ctx);
+    const int verified_variant = ctx->last_variant;      // what rpt_last_variant reports afterwards: the kernel that was CHECKED, not the un-culled one
     if (rc == RPT_OK) {
         ctx->external_plane = plane_b;
         ctx->variant = 3;
         rc = launch(ctx);
     }
+    ctx->last_variant = verified_variant;
     ctx->external_plane = saved.plane; ctx->external_rgb = saved.rgb; ctx->colour_plane = saved.colour_plane; ctx->want_owned_rgb = saved.want_rgb; ctx->variant = saved.variant;
     if (rc != RPT_OK) return rc;
     if (words) {

@@ -10,12 +10,16 @@
 //   * a job lives on the caller's stack: the caller leaves only after every item is done AND no worker holds the pointer
 //     (workers announce themselves before they read it; both sides use sequentially consistent operations).
 // The workers are never joined (the pool is leaked on purpose: a library has no safe moment to join threads at process exit).
+// fork(): the child has none of the parent's threads but inherits the pool's counters and, possibly, a mutex some worker held
+// at that instant.  A pthread_atfork child handler empties the pool (n_threads_ = 0, counters 0, no job): every parallel_for of
+// the child then takes the solo path and never touches m_ or callers_ again.
 #pragma once
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <mutex>
+#include <pthread.h>
 #include <thread>
 
 namespace rpth {
@@ -34,7 +38,7 @@ public:
         static Workers *pool = new Workers();      // leaked: see above
         return *pool;
     }
-    int threads() const { return n_threads_; }
+    int threads() const { return n_threads_.load(); }
 
     // fn(arg, i) for every i in [0, count), on the calling thread and on whichever workers show up; returns when all are done
     void parallel_for(int count, void (*fn)(void *, int), void *arg) {
@@ -45,7 +49,7 @@ public:
         job.count = count;
         job.pending.store(count);
         std::unique_lock<std::mutex> one_caller(callers_, std::defer_lock);
-        const bool shared = n_threads_ > 0 && one_caller.try_lock();     // a second submitting thread does its batch alone
+        const bool shared = n_threads_.load() > 0 && one_caller.try_lock();     // a second submitting thread does its batch alone
         if (shared) {
             job_.store(&job);
             epoch_.fetch_add(1);
@@ -72,11 +76,19 @@ private:
         for (int k = 0; k < n; k++) {
             try {
                 std::thread([this] { worker(); }).detach();
-                n_threads_++;
+                n_threads_.fetch_add(1);
             } catch (...) {
                 break;
             }
         }
+        pthread_atfork(nullptr, nullptr, [] { instance().after_fork_in_child(); });
+    }
+    // the child of a fork(): no workers exist here; whatever the counters and mutexes said in the parent is void
+    void after_fork_in_child() {
+        n_threads_.store(0);
+        job_.store(nullptr);
+        holders_.store(0);
+        sleepers_.store(0);
     }
 
     static void pause() {
@@ -118,7 +130,7 @@ private:
         }
     }
 
-    int n_threads_ = 0;
+    std::atomic<int> n_threads_{0};
     std::atomic<Job *> job_{nullptr};
     std::atomic<unsigned> epoch_{0};
     std::atomic<int> holders_{0}, sleepers_{0};

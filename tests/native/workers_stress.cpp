@@ -4,7 +4,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sys/wait.h>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 #include "../../relativitypathtracer_amd/csrc/rpt_workers.hpp"
 
@@ -35,7 +37,32 @@ static int submit(int rounds, unsigned seed) {
     return bad;
 }
 
+// fork() while a thread keeps the pool busy: the child has no workers and inherits whatever the counters (and a mutex a worker
+// may have held) said at that instant.  Its batches must still complete — on the calling thread alone (pthread_atfork child
+// handler in rpt_workers.hpp) — and it must report threads 0.
+static int fork_mode(int forks) {
+    std::atomic<bool> stop{false};
+    std::thread busy([&] { while (!stop.load()) submit(50, 7u); });
+    int bad = 0;
+    for (int f = 0; f < forks; f++) {
+        std::this_thread::sleep_for(std::chrono::microseconds(150 + 37 * (f % 11)));      // some forks catch the workers asleep, some at work
+        const pid_t pid = fork();
+        if (pid == 0) {
+            alarm(20);                                            // a child that hangs dies of SIGALRM and is counted
+            const int b = submit(200, 100u + (unsigned)f) + (rpth::Workers::instance().threads() != 0);
+            _exit(b ? 1 : 0);
+        }
+        int status = 0;
+        if (pid < 0 || waitpid(pid, &status, 0) != pid || !WIFEXITED(status) || WEXITSTATUS(status) != 0) bad++;
+    }
+    stop.store(true);
+    busy.join();
+    std::printf("threads %d forks %d bad %d\n", rpth::Workers::instance().threads(), forks, bad);
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 2 && std::strcmp(argv[1], "--fork") == 0) return fork_mode(std::atoi(argv[2]));
     const int rounds = argc > 1 ? std::atoi(argv[1]) : 20000;
     int bad_a = 0, bad_b = 0;
     std::thread ta([&] { bad_a = submit(rounds, 1u); });

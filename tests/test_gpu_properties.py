@@ -517,35 +517,35 @@ def test_bench_exchange_path_over_rccl_with_one_rank(tmp_path, split):
     flight — run as a real torch.distributed job of one rank (RPT_FORCE_DIST), camera clock running so that every
     frame differs; its own --check compares the root's last framebuffer with the oracle."""
     import json
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     exchange = "torch" if split.endswith("-torch") else "native"      # native: ONE ncclGather per frame through ctypes (rccl.py); torch: torch.distributed.gather
     split = split.split("-")[0]
     env = {**os.environ, "RPT_FORCE_DIST": "1", "RPT_BENCH_ANIMATE": "1", "RPT_SPLIT": "equal" if split == "full16" else split, "RPT_EXCHANGE": exchange}   # "4": the weighted split's root path
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "14", "--warmup", "2",
+    # the launcher owns the rendezvous (its c10d store binds port 0 itself): no port is picked, closed and passed on here
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--rdzv-backend=c10d",
+           "--rdzv-endpoint=127.0.0.1:0", "--local-addr", "127.0.0.1", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "14", "--warmup", "2",
            "--workload", "shadows", "--width", "1280", "--height", "720", "--no-cpu-baseline", "--check"]
     if split == "full16":     # the naive exchange of whole 16-byte pixels (SURVEY.md 8e), equal split
         cmd += ["--gather", "full16"]
-    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    # ONE attempt.  The child's complete output is kept in a file (and, on the GPU box, under gpurun_out/, which travels back):
+    # a launcher or a rank that dies is a red test whose words can be read afterwards.
+    log = tmp_path / f"bench_exchange_{split}_{exchange}.log"
+    with open(log, "w") as f:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=f, text=True, env=env, timeout=600, cwd=root)
+        f.write("\n---- stdout ----\n" + p.stdout)
     if p.returncode != 0:
-        # a launcher that died before or while the job ran (this test failed ONCE in some forty runs of round 3 and its message was
-        # not kept): run it once more on another port and keep the first run's words in the warnings.  A wrong FRAME is not retried:
-        # that comes back as "check" in a line of a run that returned 0.
-        import warnings
-        warnings.warn(f"bench.py under torch.distributed.run returned {p.returncode} at the first attempt:\n{p.stderr[-1500:]}")
-        s2 = socket.socket()
-        s2.bind(("127.0.0.1", 0))
-        cmd[cmd.index("--master-port") + 1] = str(s2.getsockname()[1])
-        s2.close()
-        p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
-    assert p.returncode == 0, p.stderr[-2000:]
+        keep = os.path.join(root, "gpurun_out", "failed_" + log.name)
+        try:
+            os.makedirs(os.path.dirname(keep), exist_ok=True)
+            with open(log) as src, open(keep, "w") as dst:
+                dst.write(src.read())
+        except OSError:
+            keep = str(log)
+        with open(log) as f:
+            tail = f.read()[-4096:]
+        raise AssertionError(f"bench.py under torch.distributed.run returned {p.returncode}; complete output in {keep}; its last 4 KB:\n{tail}")
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["check"] == "framebuffer rows identical to the oracle", out["check"]

@@ -31,6 +31,17 @@ def test_every_item_once_from_two_submitting_threads(tmp_path):
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
+def test_a_forked_child_computes_its_batches_alone(tmp_path):
+    """fork() in a process whose pool is busy: the child inherits the counters, not the threads; the pthread_atfork child
+    handler empties the pool, every batch of the child completes on its calling thread (before, a child could
+    deadlock on the pool's mutex or wait for holders that do not exist)."""
+    exe, p = _build(tmp_path, "workers_stress", ["-O2"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = subprocess.run([exe, "--fork", "200"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and " bad 0" in r.stdout, (r.stdout, r.stderr[-2000:])
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
 def test_thread_sanitizer_finds_no_race(tmp_path):
     exe, p = _build(tmp_path, "workers_tsan", ["-O1", "-g", "-fsanitize=thread"])
     if p.returncode != 0:
