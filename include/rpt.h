@@ -159,6 +159,16 @@ int rpt_object_screen_rect(const void *object, int interval, const float *root_b
 /* The whole record: the rectangle, then the diagonal slabs {p_lo, p_hi} on u + v and {m_lo, m_hi} on u - v that cut its
  * corners where that pays (+-3e38 = no cut); the slabs hold for |u| <= 2, |v| <= 0.55 (frames up to 4 : 1). */
 int rpt_object_screen_bounds(const void *object, int interval, const float *root_bounds_or_null, float bounds_out[8]);
+/* Both calls above return what the kernel USES: the region proposed by the outline sampling of csrc/rpt_screen_bounds.hpp if
+ * csrc/rpt_bounds_certify.hpp could PROVE it (no pixel of a frame of at most 4 : 1 outside it can make the kernel's float
+ * arithmetic report a hit of the object; the argument is in that file's header), else the full plane — the object is then
+ * tested for every pixel, as in the reference (opencl_kernel.cl:382-425).  The two calls below expose the halves, for tests
+ * and tools: the raw proposal, and the proof attempt for ANY claimed region (1 = proven, 0 = not; stats_out, if not NULL,
+ * receives {reason, segment tests used, deepest halving, boundary segments}: reason 0 proven, 1 non-finite input, 2 the
+ * boosted directions do not cover the sphere once, 3 float noise too large, 4 ray origin inside or near the shape, 5 no
+ * witness / witness outside the claim, 6 test budget exhausted, 7 a boundary point's exact ray meets the shape). */
+int rpt_object_screen_bounds_proposed(const void *object, int interval, const float *root_bounds_or_null, float bounds_out[8]);
+int rpt_certify_screen_bounds(const void *object, int interval, const float *root_bounds_or_null, const float bounds[8], int stats_out[4]);
 
 /* Render one frame and wait for it (the reference's runKernel + finish). */
 int rpt_render(rpt_ctx *ctx);

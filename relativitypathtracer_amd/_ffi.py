@@ -133,6 +133,8 @@ HIP_SYMBOLS = {
     "rpt_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "rpt_object_screen_rect": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rpt_object_screen_bounds": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "rpt_object_screen_bounds_proposed": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "rpt_certify_screen_bounds": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "rpt_verify_frame": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rpt_last_variant": (C.c_int, [C.c_void_p]),
     "rpt_set_msaa": (C.c_int, [C.c_void_p, C.c_int]),

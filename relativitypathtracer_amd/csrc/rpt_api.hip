@@ -20,6 +20,7 @@
 #include "rpt_kernels.hip.h"       /* (+ rpt_diag_walks / rpt_diag_kernels / rpt_persistent under RPT_DIAGNOSTICS) */
 #include "rpt_octree_build.hip.h"
 #include "rpt_screen_bounds.hpp"
+#include "rpt_bounds_certify.hpp"
 #include "rpt_workers.hpp"
 
 #pragma clang fp contract(off)
@@ -428,7 +429,7 @@ void rect_batch_item(void *arg, int k) {
     const float *root = nullptr;
     if (o.type == RPT_MESH && o.meshIndex >= 0 && (size_t)o.meshIndex * 6 + 5 < b.ctx->geo->host_node_bounds.size())
         root = &b.ctx->geo->host_node_bounds[(size_t)o.meshIndex * 6];
-    b.out[i] = b.ctx->rects[i] = rptb::object_rect(o, b.ctx->interval, root);
+    b.out[i] = b.ctx->rects[i] = rptb::certified_object_rect(o, b.ctx->interval, root);      // proposed by sampling, PROVEN or dropped (rpt_bounds_certify.hpp)
 }
 void build_rects(rpt_ctx *ctx, const rpt_object *objs, int count, rptb::Rect *out) {
     const bool comparable = ctx->rect_interval == ctx->interval && ctx->rect_geo_generation == ctx->geo->generation &&
@@ -683,6 +684,11 @@ int launch(rpt_ctx *ctx) {
     int v = ctx->variant == 0 ? (!ctx->has_mesh ? 44 : (ctx->latency_call || small_frame ? 43 : 41)) : ctx->variant;
     if (v == 44 && ctx->has_mesh) v = 41;          // (asked for explicitly on a scene with meshes: the full kernel)
     if (!ctx->geo->compact_ok && v != 44) v = 1;
+    // The per-object regions are PROVEN for the window |u| <= 2, |v| <= 1/2 (rpt_bounds_certify.hpp): a frame wider than 4 : 1 has
+    // pixels outside it, and beyond 2^20 pixels a side a tile's 1.5-pixel skirt is no longer large against float rounding — such
+    // frames are rendered by the un-culled kernel (same pixels, every object tested everywhere).
+    const bool window_holds_frame = 0.5f * a.aspect <= (float)rptb::cert::WINDOW_U && ctx->width <= (1 << 20) && ctx->height <= (1 << 20);
+    if (!window_holds_frame && (v == 41 || v == 43 || v == 44)) v = 3;
     const bool band_first = v == 43
 #ifdef RPT_DIAGNOSTICS
                             || v == 143 || v == 2573 || (v >= 256 && v < 1000 && (v & 8))
@@ -982,17 +988,34 @@ int rpt_set_debug_rgb(rpt_ctx *ctx, void *p) {
 
 int rpt_object_screen_rect(const void *object, int interval, const float *root_bounds_or_null, float rect_out[4]) {
     if (!object || !rect_out) return RPT_ERR_ARG;
-    const rptb::Rect r = rptb::object_rect(*(const rpt_object *)object, interval, root_bounds_or_null);
+    const rptb::Rect r = rptb::certified_object_rect(*(const rpt_object *)object, interval, root_bounds_or_null);
     rect_out[0] = r.u0; rect_out[1] = r.v0; rect_out[2] = r.u1; rect_out[3] = r.v1;
     return RPT_OK;
 }
 
 int rpt_object_screen_bounds(const void *object, int interval, const float *root_bounds_or_null, float bounds_out[8]) {
     if (!object || !bounds_out) return RPT_ERR_ARG;
-    const rptb::Rect r = rptb::object_rect(*(const rpt_object *)object, interval, root_bounds_or_null);
+    const rptb::Rect r = rptb::certified_object_rect(*(const rpt_object *)object, interval, root_bounds_or_null);
     const float v[8] = {r.u0, r.v0, r.u1, r.v1, r.p_lo, r.p_hi, r.m_lo, r.m_hi};
     for (int k = 0; k < 8; k++) bounds_out[k] = v[k];
     return RPT_OK;
+}
+
+int rpt_object_screen_bounds_proposed(const void *object, int interval, const float *root_bounds_or_null, float bounds_out[8]) {
+    if (!object || !bounds_out) return RPT_ERR_ARG;
+    const rptb::Rect r = rptb::proposed_object_rect(*(const rpt_object *)object, interval, root_bounds_or_null);
+    const float v[8] = {r.u0, r.v0, r.u1, r.v1, r.p_lo, r.p_hi, r.m_lo, r.m_hi};
+    for (int k = 0; k < 8; k++) bounds_out[k] = v[k];
+    return RPT_OK;
+}
+
+int rpt_certify_screen_bounds(const void *object, int interval, const float *root_bounds_or_null, const float bounds[8], int stats_out[4]) {
+    if (!object || !bounds) return RPT_ERR_ARG;
+    const rptb::Rect r{bounds[0], bounds[1], bounds[2], bounds[3], bounds[4], bounds[5], bounds[6], bounds[7]};
+    rptb::cert::Stats st{0, 0, 0, 0};
+    const bool ok = rptb::cert::certify(*(const rpt_object *)object, interval, root_bounds_or_null, r, &st);
+    if (stats_out) { stats_out[0] = st.reason; stats_out[1] = st.tests; stats_out[2] = st.max_depth; stats_out[3] = st.segments; }
+    return ok ? 1 : 0;
 }
 
 int rpt_set_variant(rpt_ctx *ctx, int variant) {

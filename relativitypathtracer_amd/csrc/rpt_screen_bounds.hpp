@@ -730,7 +730,8 @@ inline Rect sphere_rect(const rpt_object &o, int interval) {
     // camera that is hundreds of radii away in the object's frame (a strongly boosted sphere) the float sphere is visibly
     // larger or smaller than the exact one.  The rim is taken from a sphere that is larger by that bound.
     if (!finite3(oc) || !std::isfinite(dist)) return full_rect();
-    const double rb = 1.02 * std::sqrt(1.0 + 1.5e-6 * dist * dist);
+    // (2^-19 (|oc|^2 + 1): the bound rpt_bounds_certify.hpp DERIVES for that discriminant — the claim made here has to be provable there)
+    const double rb = 1.02 * std::sqrt(1.0 + 1.9073486328125e-6 * (dist * dist + 1.0));
     if (!(dist > 1.1 * rb) || dist > 5.0e4) return full_rect();      // (beyond 5e4 radii the float direction itself is too coarse)
     const D3 axis = mul(oc, -1.0 / dist);
     const double sa = rb / dist, ca = std::sqrt(1.0 - sa * sa);
