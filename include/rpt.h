@@ -167,6 +167,12 @@ int rpt_object_screen_bounds(const void *object, int interval, const float *root
  * receives {reason, segment tests used, deepest halving, boundary segments}: reason 0 proven, 1 non-finite input, 2 the
  * boosted directions do not cover the sphere once, 3 float noise too large, 4 ray origin inside or near the shape, 5 no
  * witness / witness outside the claim, 6 test budget exhausted, 7 a boundary point's exact ray meets the shape). */
+/* Test hook (host code): the shadow-ray cull record of mesh object `object_index` of the context's current Object[] —
+ * {half extents xyz of the root box as mesh_ray_misses_root uses them (< 0: no cull of this object), constant and slope of the
+ * segment cull's margin (slope < 0: no segment cull: the mesh's triangles are too large for it to be provable, or a matrix is
+ * too ill-conditioned), allowance of the segment's end per unit of the rest-frame origin's L1 norm, K = the mesh's largest
+ * |e1| |e2|, 1 if the mesh's lists stay inside its root box} (csrc/rpt_kernels.hip.h; csrc/rpt_api.hip: mesh_segment_cull_record). */
+int rpt_mesh_segment_cull_record(rpt_ctx *ctx, int object_index, float out[8]);
 int rpt_object_screen_bounds_proposed(const void *object, int interval, const float *root_bounds_or_null, float bounds_out[8]);
 int rpt_certify_screen_bounds(const void *object, int interval, const float *root_bounds_or_null, const float bounds[8], int stats_out[4]);
 
@@ -250,6 +256,14 @@ void rpt_free_host(void *p);
  * (in 15 floats -> out 4), 1 intersect_AABB (12 -> 5), 2 createCamRay (4 -> 3), 3 hable (3 -> 3), 4 asin / atan2 of the
  * textured-sphere (u,v) (3 -> 2), 5 the walk's pure steps: exit face of a leaf and child selection, general and fast (6 -> 12). */
 int rpt_probe(rpt_ctx *ctx, int which, const void *host_in, void *host_out, int n);
+/* Test hook, one object's functions at ray level (the oracle's counterpart: rpt_oracle_object_rays): which = 0 n 4-D rays
+ * {origin4, dir4} of object `object_index`'s rest frame through its intersector in the general form of opencl_kernel.cl:312-359 /
+ * 200-308 (8 floats in, {hit, dist, normal.xyz, uv.xy, 0} out); 1 n shadow rays {origin4, dir4, lightDist} of the camera frame
+ * through sample_light (:488-545) with light `object_index` (9 in; out 2 = occluded as the un-culled kernel decides it, and as the
+ * culled kernels do — the same wave-level segment culls as in a frame); 2 the transforms of :75-104 on n vectors (4 in, 16 out:
+ * transformPoint(InvM), transformPoint4D(Lorentz), transformDirection(InvM), applyTranspose(InvM)); 3 n primary rays given by
+ * their camera direction through the form the default kernels use (3 in, 8 out as in 0). */
+int rpt_probe_object(rpt_ctx *ctx, int which, int object_index, const float *host_in, float *host_out, int n);
 /* Test hook, the octree walk at ray level: n rays {origin.xyz, dir.xyz} in the object space of mesh object `object_index` of the
  * current Object[] go through the three walks of the product library — the reference's layouts (opencl_kernel.cl:200-308 as
  * written), the throughput walk of kernel 41 and the latency walk of kernel 43 — and host_out receives 3 x 8 floats per ray:

@@ -916,6 +916,82 @@ int rpt_oracle_octree_rays(const rpt_oracle_args *a, int object_index, const flo
     return 0;
 }
 
+
+/* ---- object-level known-answer entry points (intersect_sphere :335-359, intersect_cube :312-333,
+ * transformPoint* :75-104, sample_light :488-545) against rpt_probe_object of the HIP library ---- */
+static void scene_from_args(const rpt_oracle_args *a, Scene *sc) {
+    memset(sc, 0, sizeof *sc);
+    sc->objects = (const rpt_object *)a->objects;
+    sc->object_count = a->object_count;
+    sc->vertices = (const rpt_float3 *)a->vertices;
+    sc->normals = (const rpt_float3 *)a->normals;
+    sc->uvs = (const rpt_float2 *)a->uvs;
+    sc->triangles = (const uint32_t *)a->triangles;
+    sc->octrees = (const rpt_octree *)a->octrees;
+    sc->octreeTris = (const int32_t *)a->octreeTris;
+    sc->textures = (const uint8_t *)a->textures;
+    sc->texture_bytes = (int64_t)a->texture_bytes;
+    sc->interval = a->interval;
+}
+
+/* which = 0: n rays {origin4, dir4} (8 floats, the object's rest frame) through object `object_index` with the intersector of its
+ *            type (intersect_sphere / intersect_cube / intersect_octree); out8 = {hit, dist, normal.xyz, uv.xy, 0}
+ * which = 1: sample_light: n shadow rays {origin4, dir4, lightDist} (9 floats, camera frame) against the whole scene with light
+ *            `object_index`; out1 = index of the first occluder, or -1
+ * which = 2: the four transforms on n vectors {x, y, z, w} (4 floats): out16 = {transformPoint(InvM, xyz), 0, transformPoint4D(Lorentz, v),
+ *            transformDirection(InvM, xyz), 0, applyTranspose(InvM, xyz), 0} of object `object_index` */
+int rpt_oracle_object_rays(const rpt_oracle_args *a, int which, int object_index, const float *in, float *out, int n) {
+    if (!a || !in || !out || object_index < 0 || object_index >= a->object_count) return -1;
+    Scene sc;
+    scene_from_args(a, &sc);
+    const rpt_object *obj = &sc.objects[object_index];
+    for (int i = 0; i < n; i++) {
+        if (which == 0) {
+            const float *p = in + 8 * (size_t)i;
+            Ray4D r;
+            r.origin = F4(p[0], p[1], p[2], p[3]);
+            r.dir = F4(p[4], p[5], p[6], p[7]);
+            Hit hit;
+            memset(&hit, 0, sizeof hit);
+            hit.dist = 1e20f;
+            int h = 0;
+            switch (obj->type) {
+            case RPT_SPHERE: h = intersect_sphere(&sc, object_index, &r, &hit); break;
+            case RPT_CUBE:   h = intersect_cube(&sc, object_index, &r, &hit); break;
+            case RPT_MESH:   h = intersect_octree(&sc, object_index, &r, &hit); break;
+            default: return -1;
+            }
+            float *o = out + 8 * (size_t)i;
+            o[0] = h ? 1.0f : 0.0f;
+            o[1] = h ? hit.dist : 0.0f;
+            o[2] = h ? hit.normal.x : 0.0f; o[3] = h ? hit.normal.y : 0.0f; o[4] = h ? hit.normal.z : 0.0f;
+            o[5] = h ? hit.uv.x : 0.0f; o[6] = h ? hit.uv.y : 0.0f;
+            o[7] = 0.0f;
+        } else if (which == 1) {
+            const float *p = in + 9 * (size_t)i;
+            Ray4D r;
+            r.origin = F4(p[0], p[1], p[2], p[3]);
+            r.dir = F4(p[4], p[5], p[6], p[7]);
+            out[i] = (float)sample_light(&sc, &r, p[8], object_index);
+        } else if (which == 2) {
+            const float *p = in + 4 * (size_t)i;
+            float *o = out + 16 * (size_t)i;
+            const f3 v = F3(p[0], p[1], p[2]);
+            const f3 t0 = transformPoint(obj->InvM, v);
+            const f4 t1 = transformPoint4D(obj->Lorentz, F4(p[0], p[1], p[2], p[3]));
+            const f3 t2 = transformDirection(obj->InvM, v);
+            const f3 t3 = applyTranspose(obj->InvM, v);
+            o[0] = t0.x; o[1] = t0.y; o[2] = t0.z; o[3] = 0.0f;
+            o[4] = t1.x; o[5] = t1.y; o[6] = t1.z; o[7] = t1.w;
+            o[8] = t2.x; o[9] = t2.y; o[10] = t2.z; o[11] = 0.0f;
+            o[12] = t3.x; o[13] = t3.y; o[14] = t3.z; o[15] = 0.0f;
+        } else {
+            return -1;
+        }
+    }
+    return 0;
+}
+
 /* out4 = {side, uv'.xyz} of getOppositeBoxSide; out4b = {childIndex, uv'.xyz} of the octree child step */
 void rpt_oracle_walk_steps(const float *scaledDir3, const float *uv3, float *out4, float *out4b) {
     f3 uv = F3(uv3[0], uv3[1], uv3[2]);

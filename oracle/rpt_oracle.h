@@ -52,6 +52,8 @@ void rpt_oracle_walk_steps(const float *scaledDir3, const float *uv3, float *out
 /* opencl_kernel.cl:206-306 on n object-space rays {origin.xyz, dir.xyz} through mesh object `object_index`; out8 per ray =
  * {hit, dist, normal.xyz, uv.xy, 0} (distance re-measured from the origin of the object's frame at unit direction length). */
 int rpt_oracle_octree_rays(const rpt_oracle_args *a, int object_index, const float *rays, float *out8, int n);
+/* Object-level entry points (see rpt_oracle.c): which = 0 one object's intersector on 4-D rays, 1 sample_light, 2 the transforms. */
+int rpt_oracle_object_rays(const rpt_oracle_args *a, int which, int object_index, const float *in, float *out, int n);
 void rpt_oracle_asin_atan2(float a, float y, float x, float *out2);   /* out2 = {asin(a), atan2(y, x)} as the oracle defines them */
 
 #ifdef __cplusplus

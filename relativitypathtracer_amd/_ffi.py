@@ -133,12 +133,14 @@ HIP_SYMBOLS = {
     "rpt_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "rpt_object_screen_rect": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rpt_object_screen_bounds": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "rpt_mesh_segment_cull_record": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "rpt_object_screen_bounds_proposed": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rpt_certify_screen_bounds": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "rpt_verify_frame": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rpt_last_variant": (C.c_int, [C.c_void_p]),
     "rpt_set_msaa": (C.c_int, [C.c_void_p, C.c_int]),
     "rpt_probe_walk": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "rpt_probe_object": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "rpt_render": (C.c_int, [C.c_void_p]),
     "rpt_render_async": (C.c_int, [C.c_void_p]),
     "rpt_sync": (C.c_int, [C.c_void_p]),

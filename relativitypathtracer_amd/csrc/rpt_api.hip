@@ -62,6 +62,7 @@ struct Geometry {
     std::vector<int> node_new_index;          // reference node index -> index in the derived, breadth-first numbering
     int top_count = 0;                        // derived nodes [0, top_count) are the forest's top levels (<= RPT_TOP_MAX)
     std::vector<float> host_node_bounds;      // min.xyz,max.xyz per octree node (culling spheres of mesh roots)
+    std::vector<float> node_tri_K, node_tri_L;       // per node: the largest |e1| |e2| and the longest edge of the triangles its list names (mesh_segment_apart's margin)
     std::vector<uint8_t> node_holds_its_triangles;   // per node: every triangle of its list lies inside its box (true of a mesh's root
                                                      // unless its list also holds an earlier mesh's triangles, Mesh.cpp:16-19)
     size_t vertex_count = 0, normal_count = 0, uv_count = 0, triangle_words = 0, octree_count = 0, octree_tri_count = 0;
@@ -360,6 +361,80 @@ int build_derived_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
     return RPT_OK;
 }
 
+// The constants of mesh_segment_apart (rpt_kernels.hip.h, where the derivation is): may a shadow ray's segment to the light be
+// dropped for mesh object `o` when it stays beyond a plane of the root box, and with which margins?  Everything the argument
+// assumes about THIS object in THIS frame is checked here, in double, on the float matrices the kernel reads; if anything fails
+// the object is simply never culled (mslope < 0).
+void mesh_segment_cull_record(const rpt_ctx *ctx, const rpt_object &o, rptd::DObj &d) {
+    d.mslope = -1.0f;
+    d.mcw = d.mconst = 0.0f;
+    d.mh[0] = d.mh[1] = d.mh[2] = -1.0f;
+    d.pad2[0] = d.pad2[1] = 0.0f;
+    if (o.type != RPT_MESH || !ctx->geo->compact_ok) return;
+    const size_t mi = (size_t)o.meshIndex;
+    if (o.meshIndex < 0 || mi * 6 + 5 >= ctx->geo->host_node_bounds.size() || mi >= ctx->geo->node_tri_K.size()) return;
+    const float *nb = &ctx->geo->host_node_bounds[mi * 6];
+    const double U = 5.9604644775390625e-8;
+    // mesh_ray_misses_root: half extents about the centre the kernel reads, grown by 8u max(|lo|, |hi|)
+    const float cen[3] = {d.cbx, d.cby, d.cbz};
+    double h1 = 0.0;
+    float mh[3];
+    for (int k = 0; k < 3; k++) {
+        if (!std::isfinite(nb[k]) || !std::isfinite(nb[k + 3]) || !std::isfinite(cen[k]) || !(nb[k] <= nb[k + 3])) return;
+        const double h = std::max((double)nb[k + 3] - cen[k], (double)cen[k] - nb[k]);
+        h1 += h;
+        mh[k] = std::nextafter((float)(h + 8.0 * U * std::max(std::fabs((double)nb[k]), std::fabs((double)nb[k + 3])) + 1.0e-30), INFINITY);
+        if (!std::isfinite(mh[k])) return;
+    }
+    for (int k = 0; k < 3; k++) d.mh[k] = mh[k];
+    // mesh_segment_apart: only for a mesh whose lists stay inside its root box, with light propagation on (interval 0: no light is
+    // ever sampled, opencl_kernel.cl:572), and only if everything the derivation assumes holds for these matrices
+    if (d.mesh_in_box == 0.0f || ctx->interval != -1) return;
+    const double K = ctx->geo->node_tri_K[mi], L = ctx->geo->node_tri_L[mi];
+    double M3[3][3], I3[3][3], Mt[3], It[3], Ls[3][3], L0[3];
+    for (int r = 0; r < 3; r++) {
+        M3[r][0] = o.M[r].x; M3[r][1] = o.M[r].y; M3[r][2] = o.M[r].z; Mt[r] = o.M[r].w;
+        I3[r][0] = o.InvM[r].x; I3[r][1] = o.InvM[r].y; I3[r][2] = o.InvM[r].z; It[r] = o.InvM[r].w;
+        L0[r] = o.Lorentz[r + 1].x; Ls[r][0] = o.Lorentz[r + 1].y; Ls[r][1] = o.Lorentz[r + 1].z; Ls[r][2] = o.Lorentz[r + 1].w;
+    }
+    // c1 = ||M3 InvM3 - I||_F + 16u || |M3| |InvM3| ||_F,  c0 = |M3 InvM.t + M.t| + 16u (|| |M3| |InvM.t| || + |M.t|)
+    double r3 = 0.0, km = 0.0, rt = 0.0, mit = 0.0, mt = 0.0;
+    for (int i = 0; i < 3; i++) {
+        double t = Mt[i], ta = 0.0;
+        for (int j = 0; j < 3; j++) {
+            double v = 0.0, va = 0.0;
+            for (int k = 0; k < 3; k++) { v += M3[i][k] * I3[k][j]; va += std::fabs(M3[i][k]) * std::fabs(I3[k][j]); }
+            v -= i == j ? 1.0 : 0.0;
+            r3 += v * v;
+            km += va * va;
+            t += M3[i][j] * It[j];
+            ta += std::fabs(M3[i][j]) * std::fabs(It[j]);
+        }
+        rt += t * t;
+        mit += ta * ta;
+        mt += Mt[i] * Mt[i];
+    }
+    const double c1 = std::sqrt(r3) + 16.0 * U * std::sqrt(km), c0 = std::sqrt(rt) + 16.0 * U * (std::sqrt(mit) + std::sqrt(mt));
+    // dmin: |dw| >= (1 - |Ls^-1 L0|) / ||Ls^-1||_F for every unit light direction (dw = Ls nd - L0); halved for dw's own rounding
+    double Li[3][3];
+    if (!rptb::detail::invert3(Ls, Li)) return;
+    double cvec[3], fro = 0.0, labs = 0.0;
+    for (int i = 0; i < 3; i++) {
+        cvec[i] = Li[i][0] * L0[0] + Li[i][1] * L0[1] + Li[i][2] * L0[2];
+        for (int j = 0; j < 3; j++) { fro += Li[i][j] * Li[i][j]; labs += Ls[i][j] * Ls[i][j]; }
+        labs += L0[i] * L0[i];
+    }
+    const double cn = std::sqrt(cvec[0] * cvec[0] + cvec[1] * cvec[1] + cvec[2] * cvec[2]);
+    if (!(cn < 1.0 - 1.0e-6) || !(fro > 0.0)) return;
+    const double dmin = 0.5 * (1.0 - cn) / std::sqrt(fro);
+    if (!(16.0 * U * std::sqrt(labs) <= dmin)) return;                       // the float noise of dw itself
+    const double slope = 16.2 * K + 3.2 * U;
+    if (!(c1 <= 4.0e-4) || !(c0 <= 2.0e-5 * dmin) || !(slope <= 0.25) || !std::isfinite(c1) || !std::isfinite(c0) || !std::isfinite(L) || !std::isfinite(h1)) return;
+    d.mconst = std::nextafter((float)(slope * h1 * 1.001 + 4.0 * U * L + 1.0e-30), INFINITY);
+    d.mslope = std::nextafter((float)(slope * 1.001), INFINITY);
+    d.mcw = std::nextafter((float)(1.01 * c1 / dmin), INFINITY);
+}
+
 // Per-frame DObj records: the primary-ray origin in each object's space and what follows from it
 // (opencl_kernel.cl:314,318 / 336,341), with the kernel's operation order.
 void build_dobjs(const rpt_ctx *ctx, const rpt_object *objs, int count, rptd::DObj *out) {
@@ -409,6 +484,7 @@ void build_dobjs(const rpt_ctx *ctx, const rpt_object *objs, int count, rptd::DO
                      ? ctx->geo->node_new_index[(size_t)o.meshIndex] : 0;
         d.mesh_in_box = (o.type == RPT_MESH && o.meshIndex >= 0 && (size_t)o.meshIndex < ctx->geo->node_holds_its_triangles.size() &&
                          ctx->geo->node_holds_its_triangles[(size_t)o.meshIndex] && ctx->geo->compact_ok) ? 1.0f : 0.0f;
+        mesh_segment_cull_record(ctx, o, d);
         out[i] = d;
     }
 }
@@ -846,18 +922,33 @@ int rpt_upload_scene(rpt_ctx *ctx, const rpt_scene_desc *s) {
     }
     // Which nodes hold all of their triangles inside their own box?  (Asked of mesh roots by the shadow-segment cull: a hit on a
     // triangle is a point of that triangle.)  Indices were validated above.
+    // ... and how large are those triangles?  K = max |e1| |e2|, L = the longest edge, with e1 = fl(B - A), e2 = fl(C - A) as the walk
+    // uses them: the float error of an accepted triangle hit is bounded through them (mesh_segment_apart, rpt_kernels.hip.h).
     ctx->geo->node_holds_its_triangles.assign(s->octree_count, 0);
+    ctx->geo->node_tri_K.assign(s->octree_count, 0.0f);
+    ctx->geo->node_tri_L.assign(s->octree_count, 0.0f);
     for (size_t i = 0; i < s->octree_count; i++) {
         const rpt_octree &o = s->octrees[i];
         bool inside = o.trisCount >= 0;
+        double K = 0.0, L = 0.0;
         for (int k = o.trisIndex; inside && k < o.trisIndex + o.trisCount; k++) {
             const int t = s->octreeTris[k];
+            const rpt_float3 *vv[3];
             for (int c = 0; c < 3 && inside; c++) {
                 const rpt_float3 &v = s->vertices[s->triangles[9 * t + 3 * c]];
+                vv[c] = &v;
                 inside = v.x >= o.min.x && v.x <= o.max.x && v.y >= o.min.y && v.y <= o.max.y && v.z >= o.min.z && v.z <= o.max.z;
             }
+            if (!inside) break;
+            const float e1[3] = {vv[1]->x - vv[0]->x, vv[1]->y - vv[0]->y, vv[1]->z - vv[0]->z}, e2[3] = {vv[2]->x - vv[0]->x, vv[2]->y - vv[0]->y, vv[2]->z - vv[0]->z};
+            const double l1 = std::sqrt((double)e1[0] * e1[0] + (double)e1[1] * e1[1] + (double)e1[2] * e1[2]);
+            const double l2 = std::sqrt((double)e2[0] * e2[0] + (double)e2[1] * e2[1] + (double)e2[2] * e2[2]);
+            K = std::max(K, l1 * l2);
+            L = std::max(L, std::max(l1, l2));
         }
         ctx->geo->node_holds_its_triangles[i] = inside ? 1 : 0;
+        ctx->geo->node_tri_K[i] = std::nextafter((float)K, INFINITY);
+        ctx->geo->node_tri_L[i] = std::nextafter((float)L, INFINITY);
     }
     ctx->scene_uploaded = true;
     const int rc = rpt_set_objects(ctx, s->objects, (int)s->object_count);
@@ -998,6 +1089,19 @@ int rpt_object_screen_bounds(const void *object, int interval, const float *root
     const rptb::Rect r = rptb::certified_object_rect(*(const rpt_object *)object, interval, root_bounds_or_null);
     const float v[8] = {r.u0, r.v0, r.u1, r.v1, r.p_lo, r.p_hi, r.m_lo, r.m_hi};
     for (int k = 0; k < 8; k++) bounds_out[k] = v[k];
+    return RPT_OK;
+}
+
+int rpt_mesh_segment_cull_record(rpt_ctx *ctx, int object_index, float out[8]) {
+    if (!ctx || !out || object_index < 0 || (size_t)(object_index + 1) * sizeof(rpt_object) > ctx->host_objects.size()) return RPT_ERR_ARG;
+    const rpt_object *objs = (const rpt_object *)ctx->host_objects.data();
+    std::vector<rptd::DObj> d((size_t)object_index + 1);
+    build_dobjs(ctx, objs, object_index + 1, d.data());
+    const rptd::DObj &r = d[(size_t)object_index];
+    for (int k = 0; k < 3; k++) out[k] = r.mh[k];
+    out[3] = r.mconst; out[4] = r.mslope; out[5] = r.mcw;
+    out[6] = ctx->geo->node_tri_K.size() > (size_t)objs[object_index].meshIndex && objs[object_index].meshIndex >= 0 ? ctx->geo->node_tri_K[(size_t)objs[object_index].meshIndex] : 0.0f;
+    out[7] = r.mesh_in_box;
     return RPT_OK;
 }
 
@@ -1333,15 +1437,8 @@ int rpt_probe(rpt_ctx *ctx, int which, const void *host_in, void *host_out, int 
     return rc;
 }
 
-int rpt_probe_walk(rpt_ctx *ctx, int object_index, const float *host_rays, float *host_out, int n) {
-    if (!ctx || !host_rays || !host_out || n <= 0) return RPT_ERR_ARG;
-    if (!ctx->scene_uploaded || ctx->object_count <= 0) return fail(ctx, RPT_ERR_STATE, "rpt_probe_walk before rpt_upload_scene / rpt_set_objects");
-    if (object_index < 0 || object_index >= ctx->object_count || ctx->host_objects.size() < (size_t)(object_index + 1) * sizeof(rpt_object) ||
-        ((const rpt_object *)ctx->host_objects.data())[object_index].type != RPT_MESH)
-        return fail(ctx, RPT_ERR_ARG, "rpt_probe_walk: not a mesh object");
-    if (!ctx->geo->compact_ok) return fail(ctx, RPT_ERR_STATE, "rpt_probe_walk: this octree has no derived layout (children not consecutive)");
-    RPT_HIP(ctx, hipSetDevice(ctx->device));
-    rptd::KernelArgs a;
+// the arguments the ray-level probes need: the resident scene and the current Object[] / DObj[] (no frame, no outputs)
+static void probe_kernel_args(rpt_ctx *ctx, rptd::KernelArgs &a) {
     std::memset(&a, 0, sizeof a);
     a.dnodes = (const rptd::DNode *)ctx->geo->dnodes.ptr;
     a.dtris = (const rptd::DTri *)ctx->geo->dtris.ptr;
@@ -1358,7 +1455,22 @@ int rpt_probe_walk(rpt_ctx *ctx, int object_index, const float *host_rays, float
     a.triangles = (const uint32_t *)ctx->geo->triangles.ptr;
     a.octrees = (const rpt_octree *)ctx->geo->octrees.ptr;
     a.octreeTris = (const int32_t *)ctx->geo->octreeTris.ptr;
+    a.textures = (const uint8_t *)ctx->geo->textures.ptr;
+    a.texture_bytes = (long long)ctx->geo->textures.bytes;
     a.object_count = ctx->object_count;
+    a.interval = ctx->interval;
+}
+
+int rpt_probe_walk(rpt_ctx *ctx, int object_index, const float *host_rays, float *host_out, int n) {
+    if (!ctx || !host_rays || !host_out || n <= 0) return RPT_ERR_ARG;
+    if (!ctx->scene_uploaded || ctx->object_count <= 0) return fail(ctx, RPT_ERR_STATE, "rpt_probe_walk before rpt_upload_scene / rpt_set_objects");
+    if (object_index < 0 || object_index >= ctx->object_count || ctx->host_objects.size() < (size_t)(object_index + 1) * sizeof(rpt_object) ||
+        ((const rpt_object *)ctx->host_objects.data())[object_index].type != RPT_MESH)
+        return fail(ctx, RPT_ERR_ARG, "rpt_probe_walk: not a mesh object");
+    if (!ctx->geo->compact_ok) return fail(ctx, RPT_ERR_STATE, "rpt_probe_walk: this octree has no derived layout (children not consecutive)");
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    rptd::KernelArgs a;
+    probe_kernel_args(ctx, a);
     float *d_in = nullptr, *d_out = nullptr;
     RPT_HIP(ctx, hipMalloc((void **)&d_in, sizeof(float) * 6 * (size_t)n));
     if (hipMalloc((void **)&d_out, sizeof(float) * 24 * (size_t)n) != hipSuccess) {
@@ -1372,6 +1484,34 @@ int rpt_probe_walk(rpt_ctx *ctx, int object_index, const float *host_rays, float
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
             hipMemcpy(host_out, d_out, sizeof(float) * 24 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
             rc = fail(ctx, RPT_ERR_DEVICE, "rpt_probe_walk: device error");
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+int rpt_probe_object(rpt_ctx *ctx, int which, int object_index, const float *host_in, float *host_out, int n) {
+    if (!ctx || !host_in || !host_out || n <= 0 || which < 0 || which > 3) return RPT_ERR_ARG;
+    if (!ctx->scene_uploaded || ctx->object_count <= 0) return fail(ctx, RPT_ERR_STATE, "rpt_probe_object before rpt_upload_scene / rpt_set_objects");
+    if (object_index < 0 || object_index >= ctx->object_count) return fail(ctx, RPT_ERR_ARG, "rpt_probe_object: no such object");
+    if (!ctx->geo->compact_ok) return fail(ctx, RPT_ERR_STATE, "rpt_probe_object: this octree has no derived layout (children not consecutive)");
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    rptd::KernelArgs a;
+    probe_kernel_args(ctx, a);
+    const size_t in_floats = which == 0 ? 8 : which == 1 ? 9 : which == 2 ? 4 : 3, out_floats = which == 1 ? 2 : which == 2 ? 16 : 8;
+    float *d_in = nullptr, *d_out = nullptr;
+    RPT_HIP(ctx, hipMalloc((void **)&d_in, sizeof(float) * in_floats * (size_t)n));
+    if (hipMalloc((void **)&d_out, sizeof(float) * out_floats * (size_t)n) != hipSuccess) {
+        (void)hipFree(d_in);
+        return fail(ctx, RPT_ERR_NOMEM, "rpt_probe_object: hipMalloc");
+    }
+    int rc = RPT_OK;
+    if (hipMemcpy(d_in, host_in, sizeof(float) * in_floats * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) rc = RPT_ERR_DEVICE;
+    if (!rc) {
+        hipLaunchKernelGGL(rptd::rpt_probe_object_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, a, which, object_index, d_in, d_out, n);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+            hipMemcpy(host_out, d_out, sizeof(float) * out_floats * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(ctx, RPT_ERR_DEVICE, "rpt_probe_object: device error");
     }
     (void)hipFree(d_in);
     (void)hipFree(d_out);

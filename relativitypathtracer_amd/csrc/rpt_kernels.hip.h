@@ -65,8 +65,15 @@ struct alignas(16) DObj {
     float mesh_in_box;                       // mesh objects: 1 = every triangle the octree can report lies inside the root's box
     int root;                                // mesh objects: the root's index in the derived (breadth-first) node numbering
     float pad;
+    // the shadow-ray culls of a mesh object (mesh_ray_misses_root, mesh_segment_apart below; build_dobjs derives them per frame):
+    // half extents of the root box about (cbx, cby, cbz) grown by 8u max(|lo|, |hi|) (mh[0] < 0: no cull of this object at all);
+    // the segment cull's margin = mconst + mslope * (L1 distance of the ray origin from the centre) (mslope < 0: no segment cull);
+    // the allowance of the segment's end per unit of the rest-frame origin's L1 norm.
+    float mh[3];
+    float mconst, mslope, mcw;
+    float pad2[2];
 };
-static_assert(sizeof(DObj) == 96, "DObj");
+static_assert(sizeof(DObj) == 128, "DObj");
 
 struct KernelArgs {
     // ---- the first 64 bytes are everything a wave that hits nothing needs (its cull and its store): one scalar load at the top
@@ -713,18 +720,108 @@ RPT_DEV bool sphere_core(const rpt_object &obj, f3 rayToSphere, float c, f3 dir,
     return true;
 }
 
+// ---- The shadow-segment culls.  sample_light (opencl_kernel.cl:488-545) asks of every object but the light: is it hit at a
+// distance below lightDist?  For a wave whose lanes ALL satisfy the predicates below the answer is "no" without the normalisation
+// (a square root, three IEEE divisions) and the intersector.  The predicates are sufficient conditions in the kernel's own float
+// arithmetic; u = 2^-24, first-order bounds with the constants rounded up (numerical cross-check: tests/test_float_error_bounds.py).
+//
+// Sphere and cube (unit shapes in object space).  Notation: o = origin, D = dir (both floats, as computed above), scale =
+// fl(|D|), g = fl(D / scale) the direction the intersector works with, `dist` its float result, hit.dist = fl(dist / scale).
+//  (i) WHERE the reported hit lies.  Let P = o + g dist, exactly.  cube_core: dist = fl(fl(+-1 - o_U) / g_U) >= 0 and
+//      |fl(o_V + fl(g_V dist))| < 1 give |P_U -+ 1| <= 2.1u (1 + |o_U|), |P_V| < 1 + 2.1u + 1.1u |o_V|: P in [-m1, m1]^3 with
+//      m1 = 1 + 4u (1 + |o|max).  sphere_core: with b = fl(o' . g), c = fl(fl(|o|^2) - 1), disc = fl(fl(b b) - c), sq = fl(sqrt disc),
+//      dist = fl(b -+ sq) one finds |P|^2 = 1 + E,  E = 2 b beta + (c - c~) + u-terms of b^2, disc, sq^2 + 2 sq (beta + rho) +
+//      theta dist^2  with |beta| <= 3.1u |o| (the dot product), |c - c~| <= 4.1u |o|^2 + u, |rho| <= u |dist|, |theta| <= 8.1u
+//      (|g|^2 - 1), sq <= max(|o|, 1), |dist| <= 2 max(|o|, 1):  E <= 58u (1 + |o|^2), every |P_k| <= |P| <= 1 + 29u (1 + |o|^2).
+//  (ii) THAT it lies on the tested segment.  g_k = D_k / scale (1 + d1), hit.dist = dist / scale (1 + d2), |d1|, |d2| <= u:
+//      P_k = o_k + D_k tau_k with tau_k = hit.dist (1 + 2.1u) in [0, lightDist (1 + 2.1u)) — inside [0, s], s = fl(lightDist * 1.001
+//      + 1e-4).  So P_k lies between o_k and E_k = o_k + D_k s, and the float end point e_k = fl(o_k + fl(D_k s)) obeys
+//      |e_k - E_k| <= u (|o_k| + 2.1 |e_k|).
+//  (iii) Hence, if o_k > m and e_k > m (or both < -m) for one k, every point of the segment has |x_k| > m (1 - 2.1u) - 1.1u |o_k|,
+//      which excludes P as soon as   m >= 1 + 29u (1 + |o|^2) + 2.1u m + 1.1u |o|max   (the cube's 4u (1 + |o|max) is smaller):
+//      m = 1 + 2e-6 (1 + |o|^2)  [2e-6 = 33.6u]  does it with room for its own three float roundings.  A NaN compares false: kept.
+RPT_DEV bool unit_segment_apart(f3 origin, f3 dir, float seg_max) {
+    const float s = seg_max * 1.001f + 1.0e-4f, m = 1.0f + 2.0e-6f * (1.0f + dot(origin, origin));
+    const f3 e = origin + dir * s;
+    return ((origin.x > m) & (e.x > m)) | ((origin.x < -m) & (e.x < -m)) |
+           ((origin.y > m) & (e.y > m)) | ((origin.y < -m) & (e.y < -m)) |
+           ((origin.z > m) & (e.z > m)) | ((origin.z < -m) & (e.z < -m));
+}
+// A mesh (only one whose octree lists nothing but triangles inside the root's box: the host says which — a second mesh's lists also
+// carry the first one's triangles, Mesh.cpp:16-19).  The walk accepts a triangle where Moeller-Trumbore in float says so
+// (opencl_kernel.cl:106-126: |det| >= 1e-7, 0 <= u <= 1, v >= 0, u + v <= 1, 0 <= dist < best) and re-measures the winner's distance in
+// the rest frame: hit.dist = |M (o + g dist) - wo| / |dw| (:301-303; wo, dw = the rest-frame event and direction).
+//  (i) WHERE.  With T = A + u e1 + v e2 (a point of the triangle, up to u max(|e1|, |e2|)) and Q = o + g dist, Cramer's rule carried
+//      through the float operations gives   |Q - T| <= 27.2u tau |e1| |e2| / |det| + u (tau + 2.1 dist + 2.1 max(|e1|, |e2|))
+//      (tau = |o - A|; every numerator and the determinant are 3-term dots of one cross product: 6.8u of their operands' norms each),
+//      and |det| >= 1e-7 makes the first term <= 16.2 tau K, K = the largest |e1| |e2| of the mesh's triangles (host, at upload).
+//      tau <= t1 + h1, t1 = the L1 distance of o from the box centre, h1 = the box's half extents summed: Q lies within
+//      (16.2 K + 3.2u) (t1 + h1) + 4u L  of the root box (L = longest edge).
+//  (ii) ON THE SEGMENT.  As above Q_k = o_k + D_k sigma_k, sigma_k = (dist / scale)(1 + u).  dist / scale is NOT hit.dist here:
+//      with R3 = M3 InvM3 - I, rt = M3 InvM.t + M.t and kM = || |M3| |InvM3| ||_F the re-measured distance obeys
+//      dist / scale <= (hit.dist (1 + 7u) + (c1 |wo| + c0) / |dw|) / (1 - c1),  c1 = ||R3||_F + 16u kM,  c0 = |rt| + 16u (|| |M3| |InvM.t| || + |M.t|).
+//      The host checks c1 <= 4e-4 and c0 / dmin <= 2e-5 (dmin: a lower bound of |dw| over all unit light directions) and hands over
+//      mcw = 1.01 c1 / dmin: then sigma_k <= s = fl(lightDist * 1.001 + (1e-4 + mcw |wo|_1)).
+//  (iii) Both end points beyond the same plane of the box grown by  (16.2 K + 3.2u)(t1 + h1) + 4u L  [= mconst + mslope t1; mh
+//      already holds 8u max(|lo_k|, |hi_k|)]  + 2e-6 (|o_k| + |e_k| + |c_k|)  [the float end point, the subtraction of the centre and
+//      the compares] exclude Q.  The argument needs 16.2 K small to be of any use: the host enables this cull only for meshes
+//      with 16.2 K + 3.2u <= 0.25 (bunny.obj: 0.0046; pear.obj, whose triangles are up to half a unit long in a model five units
+//      tall: 3.1 — for such a mesh a ray within 1e-3 rad of a triangle's plane can be given ANY distance by the float test, the
+//      reference's included, and no margin short of the mesh's own size excludes that; it keeps mesh_ray_misses_root only).
+RPT_DEV bool mesh_segment_apart(const DObj &pre, f3 wo, f3 origin, f3 dir, float seg_max) {
+    const float s = seg_max * 1.001f + (1.0e-4f + pre.mcw * (__builtin_fabsf(wo.x) + __builtin_fabsf(wo.y) + __builtin_fabsf(wo.z)));
+    const f3 e = origin + dir * s;
+    const float px = origin.x - pre.cbx, py = origin.y - pre.cby, pz = origin.z - pre.cbz;     // (relative to the centre: the box is |x - c| <= mh)
+    const float ex = e.x - pre.cbx, ey = e.y - pre.cby, ez = e.z - pre.cbz;
+    const float gd = pre.mconst + pre.mslope * (__builtin_fabsf(px) + __builtin_fabsf(py) + __builtin_fabsf(pz));
+    const float gx = pre.mh[0] + gd + 2.0e-6f * (__builtin_fabsf(origin.x) + __builtin_fabsf(e.x) + __builtin_fabsf(pre.cbx));
+    const float gy = pre.mh[1] + gd + 2.0e-6f * (__builtin_fabsf(origin.y) + __builtin_fabsf(e.y) + __builtin_fabsf(pre.cby));
+    const float gz = pre.mh[2] + gd + 2.0e-6f * (__builtin_fabsf(origin.z) + __builtin_fabsf(e.z) + __builtin_fabsf(pre.cbz));
+    return ((px > gx) & (ex > gx)) | ((px < -gx) & (ex < -gx)) |
+           ((py > gy) & (ey > gy)) | ((py < -gy) & (ey < -gy)) |
+           ((pz > gz) & (ez > gz)) | ((pz < -gz) & (ez < -gz));
+}
+// ANY mesh, any ray: the walk reports nothing unless the float slab test of the root box passes (opencl_kernel.cl:128-170, 228-230),
+// and a passing test means that the exact forward ray o + t g, t > 0, meets the box grown per axis by 3.1u |b - o_k| (the six plane
+// distances are t = fl(fl(b - o_k) fl(1 / g_k)) = t_exact (1 + 3.1u); the slab logic leaves a float T > 0 between all near and far
+// distances; the exact point o + g T lies that close to every slab — rpt_bounds_certify.hpp, section 2).  g_k = D_k / scale (1 + u):
+// as a direction, D with every component perturbed by one rounding.  So the walk can be skipped where NO ray o + t D', t > 0,
+// D'_k = D_k (1 +- u), meets the box |x_k - c_k| <= H_k, H_k = half extent + 4u (max(|lo_k|, |hi_k|) + |o_k|) — decided here without
+// the normalisation and the six divisions by the separating axes of a ray and a box, in float with the roundings accounted for:
+//   h_k = mh_k + 6e-7 |o_k| >= H_k (1 + 4u)     (mh_k holds 8u max(|lo_k|, |hi_k|); 6e-7 = 10u)
+//   p_k = fl(c_k - o_k) = (c_k - o_k)(1 + u)
+//   box axes:   p_k < -h_k and D_k >= 0, or p_k > h_k and D_k <= 0   (the origin beyond a side, moving away or along it)
+//   cross axes: the LINE misses if |p_j D'_k - p_k D'_j| > H_j |D'_k| + H_k |D'_j|.  A = fl(fl(p_j D_k) - fl(p_k D_j)) is within
+//               3.2u W + u |A| of the left side, W = |p_j D_k| + |p_k D_j|; S = fl(fl(h_j |D_k|) + fl(h_k |D_j|)) (1 + u) bounds
+//               the right side: asked is  |A| > S * 1.000001 + 5e-7 W   (5e-7 = 8.4u > 3.2u + u + what S and W themselves round by).
+// A NaN or an infinity compares false: the walk runs.
+RPT_DEV bool mesh_ray_misses_root(const DObj &pre, f3 origin, f3 dir) {
+    const float px = pre.cbx - origin.x, py = pre.cby - origin.y, pz = pre.cbz - origin.z;
+    const float hx = pre.mh[0] + 6.0e-7f * __builtin_fabsf(origin.x), hy = pre.mh[1] + 6.0e-7f * __builtin_fabsf(origin.y), hz = pre.mh[2] + 6.0e-7f * __builtin_fabsf(origin.z);
+    bool miss = ((px < -hx) & (dir.x >= 0.0f)) | ((px > hx) & (dir.x <= 0.0f)) |
+                ((py < -hy) & (dir.y >= 0.0f)) | ((py > hy) & (dir.y <= 0.0f)) |
+                ((pz < -hz) & (dir.z >= 0.0f)) | ((pz > hz) & (dir.z <= 0.0f));
+    const float ax = __builtin_fabsf(dir.x), ay = __builtin_fabsf(dir.y), az = __builtin_fabsf(dir.z);
+    {   // axis x cross D: components (y, z)
+        const float m1 = py * dir.z, m2 = pz * dir.y;
+        miss = miss | (__builtin_fabsf(m1 - m2) > (hy * az + hz * ay) * 1.000001f + 5.0e-7f * (__builtin_fabsf(m1) + __builtin_fabsf(m2)));
+    }
+    {   // axis y: (z, x)
+        const float m1 = pz * dir.x, m2 = px * dir.z;
+        miss = miss | (__builtin_fabsf(m1 - m2) > (hz * ax + hx * az) * 1.000001f + 5.0e-7f * (__builtin_fabsf(m1) + __builtin_fabsf(m2)));
+    }
+    {   // axis z: (x, y)
+        const float m1 = px * dir.y, m2 = py * dir.x;
+        miss = miss | (__builtin_fabsf(m1 - m2) > (hx * ay + hy * ax) * 1.000001f + 5.0e-7f * (__builtin_fabsf(m1) + __builtin_fabsf(m2)));
+    }
+    return miss;
+}
+
 // One object against one ray given as a 4-D event + 4-D direction in the object's rest frame
 // (the general form: shadow rays, and primary rays of the V = 0 kernel).
 // seg_max > 0 (shadow rays): the caller only asks whether the object is hit at a distance below seg_max (sample_light:
-// dist < lightDist).  A hit at distance s lies at origin + dir * s (dir not yet normalised: hit.dist is measured in its
-// units, opencl_kernel.cl:328,354) ON the object, and a sphere's or a cube's surface lies inside [-1,1]^3: if, for every
-// active lane of the wave, the segment origin + dir * [0, seg_max] stays beyond one of that box's six planes (the segment's
-// bounding box against the unit box grown by a margin: three multiply-adds and twelve compares; a NaN compares false and
-// keeps the object), no lane can get an answer other than "not hit below seg_max", and the normalisation, its three IEEE
-// divisions and the intersector are skipped for the whole wave (__ballot).  A mesh gets the same treatment against its root
-// box only where the host has found that every triangle its octree lists lies inside that box (DObj.mesh_in_box, below):
-// the reference's walk accepts a triangle where the RAY meets its plane, and a second mesh's lists also hold the first
-// mesh's triangles (Mesh.cpp:16-19), which can be anywhere — such a mesh is left alone.
+// dist < lightDist); if no lane of the wave can get "yes" (unit_segment_apart / mesh_segment_apart above, __ballot), the
+// normalisation, its three IEEE divisions and the intersector are skipped for the whole wave.
 // (Measured also: the slab test with v_rcp_f32 as a second stage, and the same for mesh roots as a ray test: no
 // further gain on any scene — three quarter-rate reciprocals cost what they save)
 template <int V>
@@ -733,31 +830,13 @@ RPT_DEV bool intersect_object(const KernelArgs &a, int i, f4 origin4, f4 dir4, H
     const f3 origin = transformPoint(obj.InvM, yzw(origin4));
     f3 dir = transformDirection(obj.InvM, yzw(dir4));
     if (V >= 20 && seg_max > 0.0f && obj.type != RPT_MESH) {
-        // m: the intersectors' own float error grows with the origin's distance D (in object units) — the sphere's b^2 - c by up
-        // to ~1.5e-6 D^2 (so a "hit" can lie that much outside the unit sphere), the cube's slab products by ~4e-7 D
-        const float s = seg_max * 1.001f + 1.0e-4f, m = 1.002f + 0.75e-6f * dot(origin, origin);
-        const f3 e = origin + dir * s;
-        const bool apart = ((origin.x > m) & (e.x > m)) | ((origin.x < -m) & (e.x < -m)) |
-                           ((origin.y > m) & (e.y > m)) | ((origin.y < -m) & (e.y < -m)) |
-                           ((origin.z > m) & (e.z > m)) | ((origin.z < -m) & (e.z < -m));
-        if (__ballot(!apart) == 0ull) return false;
+        if (__ballot(!unit_segment_apart(origin, dir, seg_max)) == 0ull) return false;
     }
-    // The same for a mesh whose root box holds all the triangles its octree lists (not so for a second mesh of a scene, whose
-    // lists also carry the first one's triangles, Mesh.cpp:16-19: the host says which): a hit below seg_max is a point of one of
-    // those triangles on the segment, so a segment that stays beyond one of the box's planes cannot produce one, and the
-    // normalisation, the slab test and the walk are skipped for the whole wave.  The margin covers the slab test's and the
-    // triangle test's float error (relative to the box and to the coordinates' size).
-    if (V >= 20 && seg_max > 0.0f && obj.type == RPT_MESH && a.dobjs[i].mesh_in_box != 0.0f) {
-        const DNode &root = a.dnodes[a.dobjs[i].root];
-        const float s = seg_max * 1.001f + 1.0e-4f;
-        const f3 e = origin + dir * s;
-        const float mx = 0.002f * (root.maxx - root.minx) + 2.0e-6f * (__builtin_fabsf(origin.x) + __builtin_fabsf(e.x)) + 1.0e-6f;
-        const float my = 0.002f * (root.maxy - root.miny) + 2.0e-6f * (__builtin_fabsf(origin.y) + __builtin_fabsf(e.y)) + 1.0e-6f;
-        const float mz = 0.002f * (root.maxz - root.minz) + 2.0e-6f * (__builtin_fabsf(origin.z) + __builtin_fabsf(e.z)) + 1.0e-6f;
-        const bool apart = ((origin.x > root.maxx + mx) & (e.x > root.maxx + mx)) | ((origin.x < root.minx - mx) & (e.x < root.minx - mx)) |
-                           ((origin.y > root.maxy + my) & (e.y > root.maxy + my)) | ((origin.y < root.miny - my) & (e.y < root.miny - my)) |
-                           ((origin.z > root.maxz + mz) & (e.z > root.maxz + mz)) | ((origin.z < root.minz - mz) & (e.z < root.minz - mz));
-        if (__ballot(!apart) == 0ull) return false;
+    if (V >= 20 && seg_max > 0.0f && obj.type == RPT_MESH && a.dobjs[i].mh[0] >= 0.0f) {
+        const DObj &pre = a.dobjs[i];
+        bool idle = mesh_ray_misses_root(pre, origin, dir);
+        if (pre.mslope >= 0.0f) idle = idle | mesh_segment_apart(pre, yzw(origin4), origin, dir, seg_max);      // (wave-uniform branch)
+        if (__ballot(!idle) == 0ull) return false;
     }
     const float scale = length(dir);
     dir = dir / scale;
@@ -1289,6 +1368,63 @@ __global__ void rpt_probe_kernel(int which, const float *in, float *out, int n) 
         const int ca = octree_child_step(a), cb = octree_child_step_fast(b);
         out[12 * i + 4] = (float)ca; out[12 * i + 5] = a.x; out[12 * i + 6] = a.y; out[12 * i + 7] = a.z;
         out[12 * i + 8] = (float)cb; out[12 * i + 9] = b.x; out[12 * i + 10] = b.y; out[12 * i + 11] = b.z;
+    }
+}
+
+// Known-answer probes at OBJECT level (rpt_probe_object; the oracle's counterpart is rpt_oracle_object_rays): which =
+//   0: one 4-D ray {origin4, dir4} in the rest frame of object `object` through intersect_object, the general form every shadow ray
+//      and the V = 0 kernel's primary rays take: out 8 = {hit, dist, normal.xyz, uv.xy, 0}   (opencl_kernel.cl:312-359, 200-308)
+//   1: sample_light on a shadow ray {origin4, dir4, lightDist} of the camera frame with light `object`: out 2 = {occluded as the
+//      un-culled kernel decides it, occluded as the culled kernels decide it (segment culls, __ballot over the wave)}   (:488-545)
+//   2: the transforms on {x, y, z, w}: out 16 = transformPoint(InvM), transformPoint4D(Lorentz), transformDirection(InvM),
+//      applyTranspose(InvM) of object `object`   (:75-104)
+//   3: a primary ray with camera direction {x, y, z} (normalised here as trace() does) through intersect_object_primary, the form
+//      the default kernels use (origin and constants from the per-frame DObj record): out 8 as in 0
+__global__ __launch_bounds__(64) void rpt_probe_object_kernel(const KernelArgs a, int which, int object, const float *in, float *out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = i < n ? i : n - 1;          // (idle lanes repeat the last ray: the culled forms ballot over whole waves)
+    if (which == 0 || which == 3) {
+        Hit hit;
+        hit.dist = 1e20f;
+        hit.normal = mk3(0.0f, 0.0f, 0.0f);
+        hit.uv.x = hit.uv.y = 0.0f;
+        hit.object = -1;
+        bool h;
+        if (which == 0) {
+            const float *p = in + 8 * (size_t)j;
+            h = intersect_object<1>(a, object, mk4(p[0], p[1], p[2], p[3]), mk4(p[4], p[5], p[6], p[7]), hit);
+        } else {
+            const float *p = in + 3 * (size_t)j;
+            const f3 nd = normalize(mk3(p[0], p[1], p[2]));
+            h = intersect_object_primary<20>(a, object, mk4((float)a.interval, nd.x, nd.y, nd.z), hit);
+        }
+        if (i < n) {
+            float *o = out + 8 * (size_t)i;
+            o[0] = h ? 1.0f : 0.0f;
+            o[1] = h ? hit.dist : 0.0f;
+            o[2] = h ? hit.normal.x : 0.0f; o[3] = h ? hit.normal.y : 0.0f; o[4] = h ? hit.normal.z : 0.0f;
+            o[5] = h ? hit.uv.x : 0.0f; o[6] = h ? hit.uv.y : 0.0f;
+            o[7] = 0.0f;
+        }
+    } else if (which == 1) {
+        const float *p = in + 9 * (size_t)j;
+        const f4 o4 = mk4(p[0], p[1], p[2], p[3]), d4 = mk4(p[4], p[5], p[6], p[7]);
+        const bool plain = sample_light_occluded<1>(a, o4, d4, p[8], object);
+        const bool culled = sample_light_occluded<20>(a, o4, d4, p[8], object);
+        if (i < n) { out[2 * (size_t)i] = plain ? 1.0f : 0.0f; out[2 * (size_t)i + 1] = culled ? 1.0f : 0.0f; }
+    } else if (i < n) {
+        const float *p = in + 4 * (size_t)i;
+        float *o = out + 16 * (size_t)i;
+        const rpt_object &obj = a.objects[object];
+        const f3 v = mk3(p[0], p[1], p[2]);
+        const f3 t0 = transformPoint(obj.InvM, v);
+        const f4 t1 = transformPoint4D(obj.Lorentz, mk4(p[0], p[1], p[2], p[3]));
+        const f3 t2 = transformDirection(obj.InvM, v);
+        const f3 t3 = applyTranspose(obj.InvM, v);
+        o[0] = t0.x; o[1] = t0.y; o[2] = t0.z; o[3] = 0.0f;
+        o[4] = t1.x; o[5] = t1.y; o[6] = t1.z; o[7] = t1.w;
+        o[8] = t2.x; o[9] = t2.y; o[10] = t2.z; o[11] = 0.0f;
+        o[12] = t3.x; o[13] = t3.y; o[14] = t3.z; o[15] = 0.0f;
     }
 }
 

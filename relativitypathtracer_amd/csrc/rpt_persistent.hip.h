@@ -217,23 +217,11 @@ RPT_DEV bool shadow_uniform(const KernelArgs &a, int wave, f4 origin4, f4 dir4, 
         f3 dir = transformDirection(obj.InvM, yzw(ld));
         // the wave-level segment culls of intersect_object (rpt_kernels.hip.h), same margins
         if (obj.type != RPT_MESH) {
-            const float s = lightDist * 1.001f + 1.0e-4f, m = 1.002f + 0.75e-6f * dot(origin, origin);
-            const f3 e = origin + dir * s;
-            const bool apart = ((origin.x > m) & (e.x > m)) | ((origin.x < -m) & (e.x < -m)) |
-                               ((origin.y > m) & (e.y > m)) | ((origin.y < -m) & (e.y < -m)) |
-                               ((origin.z > m) & (e.z > m)) | ((origin.z < -m) & (e.z < -m));
-            if (__ballot(act && !(apart && lightDist > 0.0f)) == 0ull) continue;
-        } else if (a.dobjs[j].mesh_in_box != 0.0f) {
-            const DNode &root = a.dnodes[a.dobjs[j].root];
-            const float s = lightDist * 1.001f + 1.0e-4f;
-            const f3 e = origin + dir * s;
-            const float mx = 0.002f * (root.maxx - root.minx) + 2.0e-6f * (__builtin_fabsf(origin.x) + __builtin_fabsf(e.x)) + 1.0e-6f;
-            const float my = 0.002f * (root.maxy - root.miny) + 2.0e-6f * (__builtin_fabsf(origin.y) + __builtin_fabsf(e.y)) + 1.0e-6f;
-            const float mz = 0.002f * (root.maxz - root.minz) + 2.0e-6f * (__builtin_fabsf(origin.z) + __builtin_fabsf(e.z)) + 1.0e-6f;
-            const bool apart = ((origin.x > root.maxx + mx) & (e.x > root.maxx + mx)) | ((origin.x < root.minx - mx) & (e.x < root.minx - mx)) |
-                               ((origin.y > root.maxy + my) & (e.y > root.maxy + my)) | ((origin.y < root.miny - my) & (e.y < root.miny - my)) |
-                               ((origin.z > root.maxz + mz) & (e.z > root.maxz + mz)) | ((origin.z < root.minz - mz) & (e.z < root.minz - mz));
-            if (__ballot(act && !(apart && lightDist > 0.0f)) == 0ull) continue;
+            if (__ballot(act && !(unit_segment_apart(origin, dir, lightDist) && lightDist > 0.0f)) == 0ull) continue;
+        } else if (a.dobjs[j].mh[0] >= 0.0f) {
+            bool idle = mesh_ray_misses_root(a.dobjs[j], origin, dir);
+            if (a.dobjs[j].mslope >= 0.0f) idle = idle | (mesh_segment_apart(a.dobjs[j], yzw(ev), origin, dir, lightDist) && lightDist > 0.0f);
+            if (__ballot(act && !idle) == 0ull) continue;
         }
         const float scale = length(dir);
         dir = dir / scale;
@@ -752,25 +740,13 @@ RPT_DEV void render_strip_queued(const KernelArgs &a) {
                 f3 dir = transformDirection(obj.InvM, yzw(ld));
                 bool want = act;
                 if (obj.type != RPT_MESH) {
-                    const float s = lightDist * 1.001f + 1.0e-4f, m = 1.002f + 0.75e-6f * dot(origin, origin);
-                    const f3 e = origin + dir * s;
-                    const bool apart = ((origin.x > m) & (e.x > m)) | ((origin.x < -m) & (e.x < -m)) |
-                                       ((origin.y > m) & (e.y > m)) | ((origin.y < -m) & (e.y < -m)) |
-                                       ((origin.z > m) & (e.z > m)) | ((origin.z < -m) & (e.z < -m));
-                    if (__ballot(act && !(apart && lightDist > 0.0f)) == 0ull) continue;
-                } else if (a.dobjs[j].mesh_in_box != 0.0f) {
-                    // per LANE here: a lane whose segment cannot reach the box does not queue a ray (the wave-wide form of this cull
-                    // in intersect_object skips only when no lane can)
-                    const DNode &root = a.dnodes[a.dobjs[j].root];
-                    const float s = lightDist * 1.001f + 1.0e-4f;
-                    const f3 e = origin + dir * s;
-                    const float mx = 0.002f * (root.maxx - root.minx) + 2.0e-6f * (__builtin_fabsf(origin.x) + __builtin_fabsf(e.x)) + 1.0e-6f;
-                    const float my = 0.002f * (root.maxy - root.miny) + 2.0e-6f * (__builtin_fabsf(origin.y) + __builtin_fabsf(e.y)) + 1.0e-6f;
-                    const float mz = 0.002f * (root.maxz - root.minz) + 2.0e-6f * (__builtin_fabsf(origin.z) + __builtin_fabsf(e.z)) + 1.0e-6f;
-                    const bool apart = ((origin.x > root.maxx + mx) & (e.x > root.maxx + mx)) | ((origin.x < root.minx - mx) & (e.x < root.minx - mx)) |
-                                       ((origin.y > root.maxy + my) & (e.y > root.maxy + my)) | ((origin.y < root.miny - my) & (e.y < root.miny - my)) |
-                                       ((origin.z > root.maxz + mz) & (e.z > root.maxz + mz)) | ((origin.z < root.minz - mz) & (e.z < root.minz - mz));
-                    want = act && !(apart && lightDist > 0.0f);
+                    if (__ballot(act && !(unit_segment_apart(origin, dir, lightDist) && lightDist > 0.0f)) == 0ull) continue;
+                } else if (a.dobjs[j].mh[0] >= 0.0f) {
+                    // per LANE here: a lane whose ray or segment cannot reach the box does not queue a ray (the wave-wide form of this
+                    // cull in intersect_object skips only when no lane can)
+                    bool idle = mesh_ray_misses_root(a.dobjs[j], origin, dir);
+                    if (a.dobjs[j].mslope >= 0.0f) idle = idle | (mesh_segment_apart(a.dobjs[j], yzw(ev), origin, dir, lightDist) && lightDist > 0.0f);
+                    want = act && !idle;
                 }
                 const float scale = length(dir);
                 dir = dir / scale;

@@ -224,6 +224,20 @@ class Renderer:
         self._check(self._lib.rpt_probe(self._h, which, inputs.ctypes.data, out.ctypes.data, n), "rpt_probe")
         return out
 
+    def probe_object(self, which: int, object_index: int, inputs: np.ndarray) -> np.ndarray:
+        """rpt_probe_object (include/rpt.h): which = 0 (n, 8) rest-frame rays -> (n, 8); 1 (n, 9) shadow rays -> (n, 2) {un-culled, culled}
+        occlusion; 2 (n, 4) vectors -> (n, 16) the four transforms; 3 (n, 3) camera directions -> (n, 8)."""
+        inputs = np.ascontiguousarray(inputs, dtype=np.float32)
+        n = inputs.shape[0]
+        out = np.empty((n, {0: 8, 1: 2, 2: 16, 3: 8}[which]), dtype=np.float32)
+        self._check(self._lib.rpt_probe_object(self._h, int(which), int(object_index), inputs.ctypes.data, out.ctypes.data, n), "rpt_probe_object")
+        return out
+
+    def mesh_segment_cull_record(self, object_index: int) -> np.ndarray:
+        out = np.zeros(8, dtype=np.float32)
+        self._check(self._lib.rpt_mesh_segment_cull_record(self._h, int(object_index), out.ctypes.data_as(C.POINTER(C.c_float))), "rpt_mesh_segment_cull_record")
+        return out
+
     def probe_walk(self, object_index: int, rays: np.ndarray) -> np.ndarray:
         """rays (n, 6) = object-space origin and direction -> (n, 3, 8): {hit, dist, normal.xyz, uv.xy, 0} from the reference-layout
         walk, the throughput walk and the latency walk (include/rpt.h, rpt_probe_walk)."""

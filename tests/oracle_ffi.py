@@ -64,6 +64,8 @@ def lib() -> C.CDLL:
         l.rpt_oracle_walk_steps.argtypes = [FP, FP, FP, FP]
         l.rpt_oracle_octree_rays.restype = C.c_int
         l.rpt_oracle_octree_rays.argtypes = [C.POINTER(OracleArgs), C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        l.rpt_oracle_object_rays.restype = C.c_int
+        l.rpt_oracle_object_rays.argtypes = [C.POINTER(OracleArgs), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         l.rpt_oracle_asin_atan2.restype = None
         l.rpt_oracle_asin_atan2.argtypes = [C.c_float, C.c_float, C.c_float, FP]
         _lib = l
@@ -122,6 +124,29 @@ def octree_rays(scene, object_index: int, rays: np.ndarray) -> np.ndarray:
     rc = lib().rpt_oracle_octree_rays(C.byref(a), int(object_index), rays.ctypes.data, out.ctypes.data, rays.shape[0])
     if rc != 0:
         raise RuntimeError(f"rpt_oracle_octree_rays failed: {rc}")
+    return out
+
+
+def object_rays(scene, which: int, object_index: int, inputs: np.ndarray, objects: np.ndarray | None = None) -> np.ndarray:
+    """rpt_oracle_object_rays: which = 0 (n, 8) rest-frame rays through one object's intersector -> (n, 8); 1 (n, 9) shadow rays
+    {origin4, dir4, lightDist} with light `object_index` -> (n,) first occluder or -1; 2 (n, 4) vectors -> (n, 16) the four transforms."""
+    d = scene.desc()
+    a = OracleArgs()
+    if objects is not None:
+        objects = np.ascontiguousarray(objects).view(np.uint8)
+        a.objects, a.object_count = objects.ctypes.data, objects.size // 320
+    else:
+        a.objects, a.object_count = d.objects, d.object_count
+    a.vertices, a.normals, a.uvs = d.vertices, d.normals, d.uvs
+    a.triangles, a.octrees, a.octreeTris = d.triangles, d.octrees, d.octreeTris
+    a.textures, a.texture_bytes = d.textures, d.texture_bytes
+    a.interval = scene.params["interval"]
+    inputs = np.ascontiguousarray(inputs, dtype=np.float32)
+    n = inputs.shape[0]
+    out = np.empty((n, 8) if which == 0 else (n,) if which == 1 else (n, 16), dtype=np.float32)
+    rc = lib().rpt_oracle_object_rays(C.byref(a), int(which), int(object_index), inputs.ctypes.data, out.ctypes.data, n)
+    if rc != 0:
+        raise RuntimeError(f"rpt_oracle_object_rays failed: {rc}")
     return out
 
 

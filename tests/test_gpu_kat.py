@@ -233,3 +233,203 @@ def test_octree_walk_at_ray_level(scene_name):
         same = (g.view(np.uint32) == want.view(np.uint32)) | (np.isnan(g) & np.isnan(want))
         bad = np.flatnonzero(~same.all(axis=1))
         assert bad.size == 0, (name, bad.size, bad[:5], rays[bad[:2]], g[bad[:2]], want[bad[:2]])
+
+
+# ---- object-level known-answer tests (intersect_sphere, intersect_cube, transformPoint*, sample_light) -----------
+
+KAT_SCENE = """MModels/pear.obj
+MModels/bunny.obj
+Os
+ p-5,-3,10,0,0,0,0,0.5,0.5,0.5
+ l1
+ c10,10,10
+Os
+ p-1,0.5,7,0.7,0.3,1,0.2,1.5,0.4,0.9
+ c0.9,0.1,0.2
+ v0.3,0.1,-0.5
+Oc
+ p0,-4,5,0,0,0,0,10,0.5,10
+ c1,1,1
+Oc
+ p3,1,9,1.1,1,1,1,0.6,2,0.3
+ c0.2,0.9,0.2
+ v-0.6,0,0.2
+Om0
+ p2,-1.5,12,0.4,0,1,0,0.5,0.5,0.5
+ c0.85,0.86,0.40
+Om1
+ p-3,-2,9,3.14,0,1,0,12,12,12
+ c0.8,0.5,0.3
+ v0,0.2,0
+A0.2
+R
+"""
+
+
+def _kat_scene(v=(0.2, -0.1, 0.4), t=3.0):
+    from relativitypathtracer_amd import Scene
+    s = Scene()
+    s.inputScene(KAT_SCENE)
+    s.set_camera(v, t)
+    s.update_objects()
+    return s
+
+
+def _same(got, want):
+    return ((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want)))
+
+
+def _rest_frame_rays(scene, i, rng, n):
+    """4-D rays in object i's REST frame that exercise its intersector: origins outside, inside, on faces; directions at the shape,
+    tangent to it, along its faces, away from it.  Built in object space and mapped with M (so that InvM brings them back)."""
+    o = scene.objects()[i]
+    M = np.array(o["M"], dtype=np.float64).reshape(4, 4)
+    kind = int(o["type"])
+    if kind == 2:
+        node = scene.octrees()[int(o["meshIndex"])]
+        lo, hi = np.array(node["min"][:3], dtype=np.float64), np.array(node["max"][:3], dtype=np.float64)
+    else:
+        lo, hi = -np.ones(3), np.ones(3)
+    c, h = 0.5 * (lo + hi), 0.5 * (hi - lo)
+    unit = lambda v: v / np.linalg.norm(v, axis=-1, keepdims=True)      # noqa: E731
+    org = c + unit(rng.normal(size=(n, 3))) * h * np.exp(rng.uniform(np.log(1.2), np.log(40.0), size=(n, 1)))
+    inside = rng.random(n) < 0.2
+    org[inside] = c + rng.uniform(-1, 1, size=(int(inside.sum()), 3)) * h * 0.95           # inside the cube / sphere / root box (winding -1)
+    onface = rng.random(n) < 0.1
+    ax = rng.integers(0, 3, size=n)
+    org[onface, ax[onface]] = (c + h * rng.choice([-1.0, 1.0], size=(n, 1)))[onface, ax[onface]]   # exactly on a face plane
+    target = c + rng.normal(size=(n, 3)) * h * rng.choice([0.3, 1.0, 1.0, 1.5], size=(n, 1))
+    graz = rng.random(n) < 0.2
+    tang = unit(rng.normal(size=(n, 3)))
+    target[graz] = (c + unit(rng.normal(size=(n, 3))) * h * (1.0 + rng.choice([-1e-6, 0.0, 1e-6, 1e-3], size=(n, 1))))[graz]   # sphere tangents / cube edges
+    d = target - org
+    along = rng.random(n) < 0.1
+    d[along, ax[along]] = 0.0                                                               # parallel to a pair of faces
+    d[rng.random(n) < 0.1] *= -1.0                                                          # pointing away
+    d = d * np.exp(rng.uniform(-2, 2, size=(n, 1)))
+    _ = tang
+    wo = org @ M[:3, :3].T + M[:3, 3]
+    wd = d @ M[:3, :3].T
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, 0] = rng.uniform(-5, 5, size=n)
+    rays[:, 1:4] = wo
+    rays[:, 4] = rng.choice([-1.0, 0.0, -2.5], size=n)
+    rays[:, 5:8] = wd
+    return rays
+
+
+@pytest.fixture(scope="module")
+def kat():
+    from relativitypathtracer_amd.renderer import Renderer
+    scene = _kat_scene()
+    r = Renderer(0)
+    r.upload_scene(scene)
+    r.set_scene_params(scene, 64, 64)
+    yield scene, r
+    r.close()
+
+
+@pytest.mark.parametrize("obj", [0, 1, 2, 3, 4, 5])
+def test_intersectors_at_ray_level(kat, obj):
+    """intersect_sphere (opencl_kernel.cl:335-359), intersect_cube (:312-333, winding -1 for inside origins included) and
+    intersect_octree (:200-308) in the general 4-D form, ray by ray against the oracle: hit flag, distance, normal, (u, v)."""
+    scene, r = kat
+    rng = np.random.default_rng(100 + obj)
+    rays = _rest_frame_rays(scene, obj, rng, 20000)
+    want = oracle_ffi.object_rays(scene, 0, obj, rays)
+    got = r.probe_object(0, obj, rays)
+    hits = int(want[:, 0].sum())
+    assert 0.1 * len(rays) < hits < 0.95 * len(rays), hits
+    bad = np.flatnonzero(~_same(got, want).all(axis=1))
+    assert bad.size == 0, (obj, bad.size, rays[bad[:2]], got[bad[:2]], want[bad[:2]])
+
+
+def test_transforms_match_the_oracle(kat):
+    """transformPoint, transformPoint4D, transformDirection, applyTranspose (opencl_kernel.cl:75-104) on random and extreme vectors."""
+    scene, r = kat
+    rng = np.random.default_rng(5)
+    v = rng.normal(size=(8192, 4)) * np.exp(rng.uniform(-20, 20, size=(8192, 1)))
+    v[:8] = [[0, 0, 0, 0], [1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1], [-0.0, 0.0, -0.0, 0.0], [3e38, -3e38, 1e-38, 1e-45], [np.inf, 1, 1, 1]]
+    v = v.astype(np.float32)
+    for obj in range(6):
+        want = oracle_ffi.object_rays(scene, 2, obj, v)
+        got = r.probe_object(2, obj, v)
+        assert _same(got, want).all(), obj
+
+
+def test_primary_ray_form_equals_the_general_form(kat):
+    """The default kernels' primary rays take the origin and its constants from the per-frame DObj record and form only rows 1..3 of
+    Lorentz * (interval, nd) (intersect_object_primary); the reference feeds stationaryCam and the full product to the same
+    intersectors (opencl_kernel.cl:382-390).  Same hits, bit for bit, for every object type."""
+    scene, r = kat
+    rng = np.random.default_rng(9)
+    n = 30000
+    cam = rng.normal(size=(n, 3)) * [1.0, 0.6, 0.3] + [0, 0, 0.5]
+    cam = cam.astype(np.float32)
+    nd = cam / np.sqrt(((cam[:, 0] * cam[:, 0] + cam[:, 1] * cam[:, 1]) + cam[:, 2] * cam[:, 2]).astype(np.float32))[:, None]
+    nd = nd.astype(np.float32)
+    interval = scene.params["interval"]
+    any_hits = 0
+    for obj in range(6):
+        o = scene.objects()[obj]
+        l4 = np.concatenate([np.full((n, 1), interval, np.float32), nd], axis=1)
+        boosted = oracle_ffi.object_rays(scene, 2, obj, np.concatenate([l4[:, 1:4], l4[:, 0:1]], axis=1))          # (unused: order check below)
+        # transformPoint4D(Lorentz, (interval, nd)): the oracle's transform entry takes {x, y, z, w} = the 4-vector's four components in order
+        boosted = oracle_ffi.object_rays(scene, 2, obj, l4)[:, 4:8]
+        rays = np.concatenate([np.tile(np.asarray(o["stationaryCam"], dtype=np.float32), (n, 1)), boosted], axis=1)
+        want = oracle_ffi.object_rays(scene, 0, obj, rays)
+        got = r.probe_object(3, obj, cam)
+        any_hits += int(want[:, 0].sum())
+        bad = np.flatnonzero(~_same(got, want).all(axis=1))
+        assert bad.size == 0, (obj, bad.size, cam[bad[:2]], got[bad[:2]], want[bad[:2]])
+    assert any_hits > 1000
+
+
+def _shadow_rays(scene, rng, n, light):
+    """Shadow rays as trace() makes them (opencl_kernel.cl:574-596): from points on and around the objects towards the light, in waves of
+    64 lanes that share their region (so that whole waves can be culled), light distances from 'right at the origin' to 'far behind
+    every object'."""
+    objs = scene.objects()
+    Ml = np.array(objs[light]["M"], dtype=np.float64).reshape(4, 4)
+    lpos = Ml[:3, 3]
+    rays = np.zeros((n, 9), dtype=np.float32)
+    for w0 in range(0, n, 64):
+        k = min(64, n - w0)
+        j = int(rng.integers(0, len(objs)))
+        M = np.array(objs[j]["M"], dtype=np.float64).reshape(4, 4)
+        centre = M[:3, 3] + rng.normal(size=3) * rng.choice([0.0, 0.5, 3.0, 20.0])
+        p = centre + rng.normal(size=(k, 3)) * rng.choice([0.01, 0.3, 2.0])
+        target = lpos + rng.normal(size=3) * rng.choice([0.0, 0.0, 1.0, 10.0])
+        d = target - p
+        dist = np.linalg.norm(d, axis=1)
+        rays[w0:w0 + k, 0] = rng.uniform(-3, 3)
+        rays[w0:w0 + k, 1:4] = p
+        rays[w0:w0 + k, 4] = -dist                                   # (time component as trace() sets it: minus the distance)
+        rays[w0:w0 + k, 5:8] = d
+        rays[w0:w0 + k, 8] = dist * rng.choice([1.0, 1.0, 0.5, 0.05, 2.0, 30.0])
+    return rays
+
+
+@pytest.mark.parametrize("state", [((0.0, 0.0, 0.0), 0.0), ((0.2, -0.1, 0.4), 3.0), ((0.0, 0.0, 0.95), 7.0)])
+def test_sample_light_at_ray_level(state):
+    """sample_light (opencl_kernel.cl:488-545) on shadow rays the frames do and do not contain: the un-culled form equals the oracle's
+    first-occluder answer, and the culled form — unit_segment_apart, mesh_ray_misses_root, mesh_segment_apart over whole waves —
+    equals the un-culled one.  The bunny in the scene keeps its segment cull (small triangles), the pear only the ray test."""
+    from relativitypathtracer_amd.renderer import Renderer
+    scene = _kat_scene(*state)
+    r = Renderer(0)
+    r.upload_scene(scene)
+    r.set_scene_params(scene, 64, 64)
+    rec_pear, rec_bunny = r.mesh_segment_cull_record(4), r.mesh_segment_cull_record(5)
+    assert rec_pear[0] > 0 and rec_pear[4] < 0 and rec_pear[6] > 0.05, rec_pear          # ray test only: 16.2 K > 0.25
+    assert rec_bunny[0] > 0 and 0 < rec_bunny[4] < 0.01 and rec_bunny[7] == 1.0, rec_bunny
+    rng = np.random.default_rng(77)
+    rays = _shadow_rays(scene, rng, 64 * 3000, 0)
+    want = oracle_ffi.object_rays(scene, 1, 0, rays) >= 0
+    got = r.probe_object(1, 0, rays) > 0
+    r.close()
+    assert 0.05 < want.mean() < 0.95, want.mean()
+    bad = np.flatnonzero(got[:, 0] != want)
+    assert bad.size == 0, ("un-culled sample_light differs from the oracle", bad.size, rays[bad[:2]])
+    bad = np.flatnonzero(got[:, 1] != want)
+    assert bad.size == 0, ("the segment culls changed an answer", bad.size, rays[bad[:2]])
