@@ -170,9 +170,10 @@ int rpt_object_screen_bounds(const void *object, int interval, const float *root
 /* Test hook (host code): the shadow-ray cull record of mesh object `object_index` of the context's current Object[] —
  * {half extents xyz of the root box as mesh_ray_misses_root uses them (< 0: no cull of this object), constant and slope of the
  * segment cull's margin (slope < 0: no segment cull: the mesh's triangles are too large for it to be provable, or a matrix is
- * too ill-conditioned), allowance of the segment's end per unit of the rest-frame origin's L1 norm, K = the mesh's largest
- * |e1| |e2|, 1 if the mesh's lists stay inside its root box} (csrc/rpt_kernels.hip.h; csrc/rpt_api.hip: mesh_segment_cull_record). */
-int rpt_mesh_segment_cull_record(rpt_ctx *ctx, int object_index, float out[8]);
+ * too ill-conditioned), allowance of the segment's end per unit of the rest-frame origin's L1 norm and its constant part,
+ * K = the mesh's largest |e1| |e2|, L = its longest edge, 1 if the mesh's lists stay inside its root box}
+ * (csrc/rpt_kernels.hip.h: mesh_ray_misses_root, mesh_segment_apart; csrc/rpt_api.hip: mesh_segment_cull_record). */
+int rpt_mesh_segment_cull_record(rpt_ctx *ctx, int object_index, float out[10]);
 int rpt_object_screen_bounds_proposed(const void *object, int interval, const float *root_bounds_or_null, float bounds_out[8]);
 int rpt_certify_screen_bounds(const void *object, int interval, const float *root_bounds_or_null, const float bounds[8], int stats_out[4]);
 

@@ -87,6 +87,26 @@ typedef struct {
 
 static __thread rpt_oracle_stats *tls_stats;
 #define STAT(field) do { if (tls_stats) tls_stats->field++; } while (0)
+/* statistics only: when was triangle t last tested — in which walk (serial number) and in which leaf visit of that walk */
+static __thread uint32_t *tls_seen_walk, *tls_seen_leaf;
+static __thread size_t tls_seen_cap;
+static __thread uint32_t tls_walk_serial;
+static void stat_tri_test(int tri, uint32_t leaf_serial) {
+    if (!tls_stats || tri < 0) return;
+    if ((size_t)tri >= tls_seen_cap) {
+        size_t cap = tls_seen_cap ? tls_seen_cap : 4096;
+        while (cap <= (size_t)tri) cap *= 2;
+        uint32_t *a = (uint32_t *)realloc(tls_seen_walk, cap * sizeof *a), *b = a ? (uint32_t *)realloc(tls_seen_leaf, cap * sizeof *b) : NULL;
+        if (!a || !b) { if (a) tls_seen_walk = a; return; }
+        memset(a + tls_seen_cap, 0, (cap - tls_seen_cap) * sizeof *a);
+        memset(b + tls_seen_cap, 0, (cap - tls_seen_cap) * sizeof *b);
+        tls_seen_walk = a; tls_seen_leaf = b; tls_seen_cap = cap;
+    }
+    if (tls_seen_walk[tri] != tls_walk_serial) tls_stats->distinct_tri_tests++;
+    else if (tls_seen_leaf[tri] + 1 == leaf_serial) tls_stats->repeats_of_previous_leaf++;
+    tls_seen_walk[tri] = tls_walk_serial;
+    tls_seen_leaf[tri] = leaf_serial;
+}
 
 /* ---- vector helpers (built-in semantics listed in the header) ---- */
 static inline f3 F3(float x, float y, float z) { f3 r = { x, y, z }; return r; }
@@ -270,6 +290,10 @@ static int intersect_octree_core(const Scene *s, const int index, Ray newRay, f3
         return 0;
     }
     STAT(root_aabb_hits);
+    if (tls_stats && ++tls_walk_serial == 0) {      /* (serial 0 = "never": on wrap-around forget everything) */
+        memset(tls_seen_walk, 0, tls_seen_cap * sizeof *tls_seen_walk);
+        tls_walk_serial = 1;
+    }
     f3 uv = add3(newRay.origin, muls3(newRay.dir, d.x));
 
     if (d.x < 0) {
@@ -313,6 +337,7 @@ static int intersect_octree_core(const Scene *s, const int index, Ray newRay, f3
             float dist;
             f2 triUV;
             STAT(tri_tests);
+            stat_tri_test(tri, (uint32_t)steps);
             if (intersect_triangle(A, B, C, &newRay, &dist, &triUV)) {
                 if (0 <= dist && dist < hit->dist) {
                     hitTri = tri;
@@ -798,6 +823,10 @@ static void *worker_main(void *p) {
         }
     }
     if (job->want_stats) job->stats[w->tid] = local;
+    free(tls_seen_walk);
+    free(tls_seen_leaf);
+    tls_seen_walk = tls_seen_leaf = NULL;
+    tls_seen_cap = 0;
     tls_stats = NULL;
     return NULL;
 }

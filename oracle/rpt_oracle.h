@@ -37,6 +37,10 @@ typedef struct rpt_oracle_args {
 typedef struct rpt_oracle_stats {
     uint64_t shadow_rays, sphere_tests, cube_tests, octree_calls, root_aabb_hits,
              inside_starts, inside_descent_steps, descent_steps, leaf_visits, tri_tests, pixels_hit;
+    /* how often does one walk test the SAME triangle again (a triangle overlapping k leaves is listed in all of them)?
+     * distinct_tri_tests: triangles tested at least once per walk, summed over walks (tri_tests - this = repeated tests);
+     * repeats_of_previous_leaf: repeated tests whose triangle was also in the list of the leaf visited immediately before. */
+    uint64_t distinct_tri_tests, repeats_of_previous_leaf;
 } rpt_oracle_stats;
 
 /* Render rows [row_begin,row_end) with `threads` host threads. stats may be NULL. 0 = ok. */

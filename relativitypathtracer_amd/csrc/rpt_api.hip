@@ -367,9 +367,9 @@ int build_derived_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
 // the object is simply never culled (mslope < 0).
 void mesh_segment_cull_record(const rpt_ctx *ctx, const rpt_object &o, rptd::DObj &d) {
     d.mslope = -1.0f;
-    d.mcw = d.mconst = 0.0f;
+    d.mcw = d.mconst = d.ms0 = 0.0f;
     d.mh[0] = d.mh[1] = d.mh[2] = -1.0f;
-    d.pad2[0] = d.pad2[1] = 0.0f;
+    d.pad2 = 0.0f;
     if (o.type != RPT_MESH || !ctx->geo->compact_ok) return;
     const size_t mi = (size_t)o.meshIndex;
     if (o.meshIndex < 0 || mi * 6 + 5 >= ctx->geo->host_node_bounds.size() || mi >= ctx->geo->node_tri_K.size()) return;
@@ -429,10 +429,11 @@ void mesh_segment_cull_record(const rpt_ctx *ctx, const rpt_object &o, rptd::DOb
     const double dmin = 0.5 * (1.0 - cn) / std::sqrt(fro);
     if (!(16.0 * U * std::sqrt(labs) <= dmin)) return;                       // the float noise of dw itself
     const double slope = 16.2 * K + 3.2 * U;
-    if (!(c1 <= 4.0e-4) || !(c0 <= 2.0e-5 * dmin) || !(slope <= 0.25) || !std::isfinite(c1) || !std::isfinite(c0) || !std::isfinite(L) || !std::isfinite(h1)) return;
+    if (!(c1 <= 4.0e-4) || !(c0 <= 0.1 * dmin) || !(slope <= 0.25) || !std::isfinite(c1) || !std::isfinite(c0) || !std::isfinite(L) || !std::isfinite(h1)) return;
     d.mconst = std::nextafter((float)(slope * h1 * 1.001 + 4.0 * U * L + 1.0e-30), INFINITY);
     d.mslope = std::nextafter((float)(slope * 1.001), INFINITY);
     d.mcw = std::nextafter((float)(1.01 * c1 / dmin), INFINITY);
+    d.ms0 = std::nextafter((float)(1.0e-4 + 1.01 * c0 / dmin), INFINITY);
 }
 
 // Per-frame DObj records: the primary-ray origin in each object's space and what follows from it
@@ -1092,16 +1093,19 @@ int rpt_object_screen_bounds(const void *object, int interval, const float *root
     return RPT_OK;
 }
 
-int rpt_mesh_segment_cull_record(rpt_ctx *ctx, int object_index, float out[8]) {
+int rpt_mesh_segment_cull_record(rpt_ctx *ctx, int object_index, float out[10]) {
     if (!ctx || !out || object_index < 0 || (size_t)(object_index + 1) * sizeof(rpt_object) > ctx->host_objects.size()) return RPT_ERR_ARG;
     const rpt_object *objs = (const rpt_object *)ctx->host_objects.data();
     std::vector<rptd::DObj> d((size_t)object_index + 1);
     build_dobjs(ctx, objs, object_index + 1, d.data());
     const rptd::DObj &r = d[(size_t)object_index];
+    const int mi = objs[object_index].meshIndex;
+    const bool known = objs[object_index].type == RPT_MESH && mi >= 0 && (size_t)mi < ctx->geo->node_tri_K.size();
     for (int k = 0; k < 3; k++) out[k] = r.mh[k];
-    out[3] = r.mconst; out[4] = r.mslope; out[5] = r.mcw;
-    out[6] = ctx->geo->node_tri_K.size() > (size_t)objs[object_index].meshIndex && objs[object_index].meshIndex >= 0 ? ctx->geo->node_tri_K[(size_t)objs[object_index].meshIndex] : 0.0f;
-    out[7] = r.mesh_in_box;
+    out[3] = r.mconst; out[4] = r.mslope; out[5] = r.mcw; out[6] = r.ms0;
+    out[7] = known ? ctx->geo->node_tri_K[(size_t)mi] : 0.0f;
+    out[8] = known ? ctx->geo->node_tri_L[(size_t)mi] : 0.0f;
+    out[9] = r.mesh_in_box;
     return RPT_OK;
 }
 

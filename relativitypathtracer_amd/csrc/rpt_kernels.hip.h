@@ -71,7 +71,8 @@ struct alignas(16) DObj {
     // the allowance of the segment's end per unit of the rest-frame origin's L1 norm.
     float mh[3];
     float mconst, mslope, mcw;
-    float pad2[2];
+    float ms0;                               // the constant part of that allowance (1e-4 + what the object's own translation costs)
+    float pad2;
 };
 static_assert(sizeof(DObj) == 128, "DObj");
 
@@ -760,8 +761,8 @@ RPT_DEV bool unit_segment_apart(f3 origin, f3 dir, float seg_max) {
 //  (ii) ON THE SEGMENT.  As above Q_k = o_k + D_k sigma_k, sigma_k = (dist / scale)(1 + u).  dist / scale is NOT hit.dist here:
 //      with R3 = M3 InvM3 - I, rt = M3 InvM.t + M.t and kM = || |M3| |InvM3| ||_F the re-measured distance obeys
 //      dist / scale <= (hit.dist (1 + 7u) + (c1 |wo| + c0) / |dw|) / (1 - c1),  c1 = ||R3||_F + 16u kM,  c0 = |rt| + 16u (|| |M3| |InvM.t| || + |M.t|).
-//      The host checks c1 <= 4e-4 and c0 / dmin <= 2e-5 (dmin: a lower bound of |dw| over all unit light directions) and hands over
-//      mcw = 1.01 c1 / dmin: then sigma_k <= s = fl(lightDist * 1.001 + (1e-4 + mcw |wo|_1)).
+//      The host checks c1 <= 4e-4 and hands over mcw = 1.01 c1 / dmin and ms0 = 1e-4 + 1.01 c0 / dmin (dmin: a lower bound of |dw|
+//      over all unit light directions): then sigma_k <= s = fl(lightDist * 1.001 + (ms0 + mcw |wo|_1)).
 //  (iii) Both end points beyond the same plane of the box grown by  (16.2 K + 3.2u)(t1 + h1) + 4u L  [= mconst + mslope t1; mh
 //      already holds 8u max(|lo_k|, |hi_k|)]  + 2e-6 (|o_k| + |e_k| + |c_k|)  [the float end point, the subtraction of the centre and
 //      the compares] exclude Q.  The argument needs 16.2 K small to be of any use: the host enables this cull only for meshes
@@ -769,7 +770,7 @@ RPT_DEV bool unit_segment_apart(f3 origin, f3 dir, float seg_max) {
 //      tall: 3.1 — for such a mesh a ray within 1e-3 rad of a triangle's plane can be given ANY distance by the float test, the
 //      reference's included, and no margin short of the mesh's own size excludes that; it keeps mesh_ray_misses_root only).
 RPT_DEV bool mesh_segment_apart(const DObj &pre, f3 wo, f3 origin, f3 dir, float seg_max) {
-    const float s = seg_max * 1.001f + (1.0e-4f + pre.mcw * (__builtin_fabsf(wo.x) + __builtin_fabsf(wo.y) + __builtin_fabsf(wo.z)));
+    const float s = seg_max * 1.001f + (pre.ms0 + pre.mcw * (__builtin_fabsf(wo.x) + __builtin_fabsf(wo.y) + __builtin_fabsf(wo.z)));
     const f3 e = origin + dir * s;
     const float px = origin.x - pre.cbx, py = origin.y - pre.cby, pz = origin.z - pre.cbz;     // (relative to the centre: the box is |x - c| <= mh)
     const float ex = e.x - pre.cbx, ey = e.y - pre.cby, ez = e.z - pre.cbz;

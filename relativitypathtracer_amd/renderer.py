@@ -234,7 +234,7 @@ class Renderer:
         return out
 
     def mesh_segment_cull_record(self, object_index: int) -> np.ndarray:
-        out = np.zeros(8, dtype=np.float32)
+        out = np.zeros(10, dtype=np.float32)
         self._check(self._lib.rpt_mesh_segment_cull_record(self._h, int(object_index), out.ctypes.data_as(C.POINTER(C.c_float))), "rpt_mesh_segment_cull_record")
         return out
 

@@ -29,7 +29,8 @@ class OracleArgs(C.Structure):
 
 
 STAT_FIELDS = ["shadow_rays", "sphere_tests", "cube_tests", "octree_calls", "root_aabb_hits", "inside_starts",
-               "inside_descent_steps", "descent_steps", "leaf_visits", "tri_tests", "pixels_hit"]
+               "inside_descent_steps", "descent_steps", "leaf_visits", "tri_tests", "pixels_hit",
+               "distinct_tri_tests", "repeats_of_previous_leaf"]
 
 
 class OracleStats(C.Structure):

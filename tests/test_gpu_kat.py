@@ -237,8 +237,9 @@ def test_octree_walk_at_ray_level(scene_name):
 
 # ---- object-level known-answer tests (intersect_sphere, intersect_cube, transformPoint*, sample_light) -----------
 
-KAT_SCENE = """MModels/pear.obj
-MModels/bunny.obj
+KAT_SCENE = """MModels/bunny.obj
+MModels/pear.obj
+TTextures/soccer.jpg
 Os
  p-5,-3,10,0,0,0,0,0.5,0.5,0.5
  l1
@@ -246,6 +247,7 @@ Os
 Os
  p-1,0.5,7,0.7,0.3,1,0.2,1.5,0.4,0.9
  c0.9,0.1,0.2
+ t0
  v0.3,0.1,-0.5
 Oc
  p0,-4,5,0,0,0,0,10,0.5,10
@@ -254,10 +256,10 @@ Oc
  p3,1,9,1.1,1,1,1,0.6,2,0.3
  c0.2,0.9,0.2
  v-0.6,0,0.2
-Om0
+Om1
  p2,-1.5,12,0.4,0,1,0,0.5,0.5,0.5
  c0.85,0.86,0.40
-Om1
+Om0
  p-3,-2,9,3.14,0,1,0,12,12,12
  c0.8,0.5,0.3
  v0,0.2,0
@@ -340,6 +342,9 @@ def test_intersectors_at_ray_level(kat, obj):
     got = r.probe_object(0, obj, rays)
     hits = int(want[:, 0].sum())
     assert 0.1 * len(rays) < hits < 0.95 * len(rays), hits
+    o = scene.objects()[obj]
+    if int(o["type"]) == 0 and int(o["textureIndex"]) == -1:
+        want[:, 5:7] = 0.0          # the (u, v) of a sphere hit is only ever read by the texture fetch: not evaluated for untextured spheres
     bad = np.flatnonzero(~_same(got, want).all(axis=1))
     assert bad.size == 0, (obj, bad.size, rays[bad[:2]], got[bad[:2]], want[bad[:2]])
 
@@ -380,6 +385,8 @@ def test_primary_ray_form_equals_the_general_form(kat):
         want = oracle_ffi.object_rays(scene, 0, obj, rays)
         got = r.probe_object(3, obj, cam)
         any_hits += int(want[:, 0].sum())
+        if int(o["type"]) == 0 and int(o["textureIndex"]) == -1:
+            want[:, 5:7] = 0.0
         bad = np.flatnonzero(~_same(got, want).all(axis=1))
         assert bad.size == 0, (obj, bad.size, cam[bad[:2]], got[bad[:2]], want[bad[:2]])
     assert any_hits > 1000
@@ -421,8 +428,11 @@ def test_sample_light_at_ray_level(state):
     r.upload_scene(scene)
     r.set_scene_params(scene, 64, 64)
     rec_pear, rec_bunny = r.mesh_segment_cull_record(4), r.mesh_segment_cull_record(5)
-    assert rec_pear[0] > 0 and rec_pear[4] < 0 and rec_pear[6] > 0.05, rec_pear          # ray test only: 16.2 K > 0.25
-    assert rec_bunny[0] > 0 and 0 < rec_bunny[4] < 0.01 and rec_bunny[7] == 1.0, rec_bunny
+    # the pear: triangles up to half a unit long in a model five units tall, 16.2 K = 3.1 — no margin short of the mesh's own size
+    # makes a segment cull provable, it keeps the ray test only.  (As the scene's SECOND mesh its lists also carry the bunny's
+    # triangles, Mesh.cpp:16-19 — which happen to lie inside the pear's root box.)
+    assert rec_pear[0] > 0 and rec_pear[4] < 0 and rec_pear[7] > 0.05, rec_pear
+    assert rec_bunny[0] > 0 and 0 < rec_bunny[4] < 0.01 and rec_bunny[9] == 1.0 and 1e-4 <= rec_bunny[6] < 1e-2, rec_bunny
     rng = np.random.default_rng(77)
     rays = _shadow_rays(scene, rng, 64 * 3000, 0)
     want = oracle_ffi.object_rays(scene, 1, 0, rays) >= 0
