@@ -80,19 +80,42 @@ def algorithmic_bytes(width, height, n_objects):
     return 16 * width * height + 320 * n_objects
 
 
+def host_cpus():
+    """(logical CPUs this process may run on, distinct physical cores among them) — from sched_getaffinity and the
+    (physical id, core id) pairs of /proc/cpuinfo; the second is None where /proc/cpuinfo does not say."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except Exception:
+        allowed = list(range(os.cpu_count() or 1))
+    cores = set()
+    try:
+        cpu, phys, core = None, None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f.read().split("\n") + [""]:
+                if line.startswith("processor"):
+                    cpu, phys, core = int(line.split(":")[1]), None, None
+                elif line.startswith("physical id"):
+                    phys = int(line.split(":")[1])
+                elif line.startswith("core id"):
+                    core = int(line.split(":")[1])
+                elif line.strip() == "" and cpu is not None:
+                    if cpu in allowed and core is not None:
+                        cores.add((phys, core))
+                    cpu = None
+    except Exception:
+        cores = set()
+    return len(allowed), (len(cores) or None)
+
+
 def cpu_baseline(scene, width, height, budget_s=12.0):
     """Time the oracle (the CPU restatement of the reference path) on this host: whole frames of
-    the SAME workload, repeated until ~budget_s of wall time, all hardware threads, plus one
+    the SAME workload, repeated until ~budget_s of wall time, one thread per physical core of this process's affinity mask, plus one
     single-thread frame.  Reported next to the GPU number; it is not the target."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi
-    threads = os.cpu_count() or 1
-    try:
-        threads = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    # the GPU box gives one GPU's share of the host: 16 cores (more threads than that only fight each other)
-    threads = max(1, min(threads, int(os.environ.get("RPT_CPU_THREADS", "16"))))
+    affinity, physical = host_cpus()
+    # one thread per physical core this process may run on (BASELINE.md §3); RPT_CPU_THREADS overrides
+    threads = max(1, int(os.environ.get("RPT_CPU_THREADS", physical or affinity or 1)))
     oracle_ffi.render(scene, width, min(height, 64), want_rgb=False, threads=threads)   # page in
     frames, t0 = 0, time.perf_counter()
     while True:
@@ -119,6 +142,7 @@ def cpu_baseline(scene, width, height, budget_s=12.0):
         pass
     return {
         "value": round(mt, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "affinity_cpus": affinity, "physical_cores": physical, "threads_used": threads,
         "sample": f"{frames} whole frame(s) of the same workload ({width}x{height}), {el:.1f} s wall, {threads} threads; "
                   f"1-thread figure on the middle quarter band: {st:.3f} Mrays/s",
         "ms_per_frame": round(el / frames * 1e3, 2), "single_thread_mrays": round(st, 3), "cpu": cpu_model,
@@ -137,19 +161,25 @@ def library_sha256():
         return None
 
 
-def measured_traffic(workload, width, height):
-    """HBM bytes per frame from a committed rocprofv3 PMC summary (tools/profile.sh + tools/pmc_summary.py: separate
-    --pmc passes, FETCH_SIZE doubled on gfx950, WRITE_SIZE as is) — ONLY if that summary was taken on this very build of
-    librpt_hip.so (recorded hash == running hash); otherwise None: counters cannot be collected from inside this process,
-    and a number from another build would be stale."""
+def measured_traffic(workload, width, height, kernel=None):
+    """HBM bytes per launch of `kernel` (its full name, e.g. rpt_render_kernel_ballot_first_w5) from a committed rocprofv3 PMC
+    summary (tools/profile.sh + tools/pmc_summary.py: separate --pmc passes, FETCH_SIZE doubled on gfx950, WRITE_SIZE as is; one
+    block per kernel) — ONLY if that summary was taken on this very build of librpt_hip.so (recorded hash == running hash);
+    otherwise None: counters cannot be collected from inside this process, and a number from another build would be stale."""
     import glob
     mine = library_sha256()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_{width}x{height}_pmc_summary.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
-            if mine and d.get("build", {}).get("librpt_hip_sha256") == mine:
-                return int(sum(v for k, v in d["derived"].items() if k.startswith("hbm_"))), os.path.relpath(path, ROOT)
+            if not (mine and d.get("build", {}).get("librpt_hip_sha256") == mine):
+                continue
+            if "kernels" in d:                       # round 4 on: one block per kernel
+                blk = d["kernels"].get(kernel)
+                if blk is None:
+                    continue
+                return int(sum(v for k, v in blk["derived"].items() if k.startswith("hbm_"))), os.path.relpath(path, ROOT)
+            return int(sum(v for k, v in d["derived"].items() if k.startswith("hbm_"))), os.path.relpath(path, ROOT)      # (rounds 1-3: kernels blended)
         except Exception:
             continue
     return None, None
@@ -205,7 +235,10 @@ def dry_run(args):
                           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
                           "config": {"workload": f"Scenes/{args.workload}.txt {args.width}x{args.height}"},
                           "comm": {"backend": "gloo" if world > 1 else None, "world_size": world,
-                                   "ranks_in_group": td.get_world_size() if world > 1 else 1}}), flush=True)
+                                   "ranks_in_group": td.get_world_size() if world > 1 else 1,
+                                   # a real N > 1 run also times BASELINE config 5 in the three arrangements (main(): config5)
+                                   "config5": None if world == 1 else {"workload": "Scenes/bunny.txt 7680x4320 (BASELINE config 5)", "ms_per_frame": None,
+                                                                       "chosen": None, "dry_run": True}}}), flush=True)
     if world > 1:
         td.destroy_process_group()
 
@@ -344,17 +377,26 @@ def main():
         rr._check(rr._lib.rpt_timing_end_frames(rr._h, buf, capacity, C.byref(nfr)), "rpt_timing_end_frames")
         return list(buf[:nfr.value])
 
+    batch_ms = []        # per-step time of each fifth of the last timed region (timed() fills it)
+
     def timed(steps):
         """K steps bracketed by barrier + device sync; returns (wall s, per-launch durations in ms) of this rank."""
         for rr in renderers:
             rr._check(rr._lib.rpt_timing_begin(rr._h, steps), "rpt_timing_begin")
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        nb = min(5, steps)
+        marks, stamps = {(steps * (b + 1)) // nb for b in range(nb - 1)}, [t0]       # batch boundaries INSIDE the one timed region
+        for k in range(steps):
             step()
+            if k + 1 in marks:
+                stamps.append(time.perf_counter())        # (no sync: a slot is reused only when its frame is done, so in steady state frames are submitted at the pace they finish)
         submit = time.perf_counter() - t0
         barrier()
         wall = time.perf_counter() - t0
+        stamps.append(t0 + wall)
+        edges = [0] + sorted(marks) + [steps]
+        batch_ms[:] = [(stamps[b + 1] - stamps[b]) / max(edges[b + 1] - edges[b], 1) * 1e3 for b in range(len(stamps) - 1)]
         if rank == 0 and os.environ.get("RPT_BENCH_VERBOSE") == "1":
             print(f"[bench] host submission {submit / steps * 1e3:.4f} ms/step, wall {wall / steps * 1e3:.4f} ms/step", file=sys.stderr)
         launches = []
@@ -390,6 +432,7 @@ def main():
         for _ in range(frame.depth):      # every slot holds the still frame again
             step()
     elapsed, launches = timed(args.steps)     # launch durations: HIP events on each launch's own stream
+    headline_batches = list(batch_ms)
     kernel_ms = sum(launches) / max(len(launches), 1)
     kernel_sum_ms = sum(launches)
     kernel_name = kernel_label(frame.slots[0].r.last_variant())        # what the timed launches were made with
@@ -420,6 +463,32 @@ def main():
         frame.last = frame.slots[0]
         frame.slots[0].frames += nb
 
+    # N > 1: the one shipped workload where sharding can pay — BASELINE config 5, Scenes/bunny.txt at 7680x4320 (0.28 ms per frame on one
+    # GPU; the 4K headline frame is shorter than one gather, so its curve is expected to be flat: README.md) — timed in the three
+    # arrangements after the headline.  Every rank runs the same collectives.  RPT_BENCH_CONFIG5=0 skips it, =WxH changes its size
+    # (rehearsals on one GPU over gloo use a smaller frame).
+    config5 = None
+    c5 = os.environ.get("RPT_BENCH_CONFIG5", "7680x4320")
+    if (n > 1 or force_dist) and c5 != "0" and args.workload == "bunny" and not animate:
+        W5, H5 = (int(x) for x in c5.split("x"))
+        if (W5, H5) != (W, H):
+            barrier()
+            for rr in renderers:
+                rr.set_scene_params(scene, W5, H5)
+            model5, info5 = rdist.calibrate_split(renderers, scene, W5, H5, rank, n, frames_per_exchange=args.frames_per_exchange, comm=comm)
+            cands5 = [None, 0] + sorted({model5 or 4})
+            best5, tried5 = rdist.autotune_split(renderers, scene, W5, H5, rank, n, cands5, frames_per_exchange=args.frames_per_exchange,
+                                                 force_gather=force_dist, rounds=6, comm=comm)
+            name5 = lambda c: "equal" if c is None else ("solo" if c == 0 else f"weighted_root_run_{c}")      # noqa: E731
+            config5 = {"workload": f"Scenes/bunny.txt {W5}x{H5} (BASELINE config 5), {n} ranks",
+                       "ms_per_frame": {name5(c): round(v * 1e3, 4) for c, v in tried5.items()}, "chosen": name5(best5),
+                       "value_chosen": round(W5 * H5 / tried5[best5] / 1e6, 2), "unit": "Mrays/s", "split_calibration": info5,
+                       "note": "max over ranks of the wall time per frame, frames in flight; equal = tile k -> rank k mod N, solo = rank 0 renders everything, "
+                               "weighted = rank 0 renders its larger share in place"}
+            for rr in renderers:
+                rr.set_scene_params(scene, W, H)
+            barrier()
+
     if n > 1:
         tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
         td.all_reduce(tt, op=td.ReduceOp.MAX)
@@ -449,6 +518,10 @@ def main():
                       else f"Mrays/s (primary rays) on Scenes/{scene_name}.txt at {W}x{H}",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+            # the same region cut into fifths by host time stamps at submission (no extra synchronisation): the median fifth is what a
+            # longer run converges to — a 20-step region is 2 ms long and starts on an idle device, its first fifth carries the ramp
+            "ms_per_step_median_of_batches": (lambda v: round(sorted(v)[len(v) // 2], 4) if v else None)(headline_batches),
+            "ms_per_step_batches": [round(x, 4) for x in headline_batches],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Scenes/{scene_name}.txt {W}x{H}, camera v={list(vel)} t={t}, interval={scene.params['interval']}, "
                                    f"mesh=Models/bunny.obj (StanfordBunny.obj is missing from the reference)" if scene_name == "bunny"
@@ -490,33 +563,43 @@ def main():
                          "note": "16 B/pixel written + 320 B/object read per launch (SURVEY.md §8d); the path is "
                                  "latency/VALU-bound by construction, HBM fraction reported because it is the contract"},
         }
-        # HBM traffic of the same launch: rocprofv3 PMC passes of this command, quoted only when taken on THIS build
-        if n == 1 and not force_dist and args.variant == 0:
-            traffic, source = measured_traffic(args.workload, W, H)
-            out["roofline"]["traffic"] = traffic
-            out["roofline"]["traffic_source"] = (f"{source} (rocprofv3 --pmc of this command on this build of librpt_hip.so: recorded hash matches)"
-                                                 if source else "no committed PMC summary was taken on this build of librpt_hip.so")
         device_key = f"frac_device_{frame.depth}_in_flight"
         rf = out["roofline"]
         rf[device_key] = rf["frac"]
         rf["device_in_flight"] = {"achieved": rf["achieved"], "frac": rf["frac"], "launch_ms": rf["launch_ms"], "launches_overlapped": rf["launches_overlapped"],
-                                  "kernel": kernel_name, "note": rf["regime"]}
+                                  "kernel": kernel_name, "note": rf["regime"], "traffic": None}
+        rf["describes"] = f"device level, {frame.depth} frames in flight ({kernel_name})"
         if blocking_kernel_ms:
             a1 = alg / (blocking_kernel_ms * 1e-3) / 1e9
-            # roofline.frac / achieved / launch_ms are the KERNEL-ALONE figures (the contract's "dominant kernel" fraction)
+            # roofline.frac / achieved / launch_ms / kernel / traffic are the KERNEL-ALONE figures (the contract's "dominant kernel"
+            # fraction): ONE kernel in ONE regime.  `value` and ms_per_step come from the frames in flight; their device-level
+            # fraction, kernel and traffic are the block roofline.device_in_flight.  (r02 -> r03 changed what the top-level keys
+            # mean; `describes` says it in the line itself.)
             rf.update({"achieved": round(a1, 2), "frac": round(a1 / HBM_PEAK_GBS, 5), "frac_kernel_alone": round(a1 / HBM_PEAK_GBS, 5),
                        "launch_ms": round(blocking_kernel_ms, 4), "launches_overlapped": 1.0,
                        "kernel": blocking_kernel_name,
+                       "describes": f"the kernel alone: {blocking_kernel_name}, one launch at a time (the blocking rpt_render); value / ms_per_step are "
+                                    f"the frames in flight, see roofline.device_in_flight ({kernel_name})",
                        "regime": "one launch at a time, nothing overlapped (the blocking rpt_render): algorithmic bytes / the launch's own HIP-event duration"})
             rf["frac_blocking"] = rf["frac"]          # (round 2's name for the same number)
         else:
             rf["frac_kernel_alone"] = None
             rf["note_regime"] = "N > 1: no kernel-alone measurement in this run; frac is the device-level figure"
+        # HBM traffic: rocprofv3 PMC passes of this command, quoted only when taken on THIS build, per kernel — the block of the
+        # kernel each figure names
+        if n == 1 and not force_dist and args.variant == 0:
+            short = lambda label: label.split(" ")[0]          # noqa: E731  ("rpt_render_kernel_ballot_w5 (41)" -> the name)
+            traffic, source = measured_traffic(args.workload, W, H, short(rf["kernel"]))
+            rf["traffic"] = traffic
+            rf["traffic_source"] = (f"{source}, block {short(rf['kernel'])} (rocprofv3 --pmc of this command on this build of librpt_hip.so: recorded hash matches)"
+                                    if source else "no committed PMC summary was taken on this build of librpt_hip.so")
+            rf["device_in_flight"]["traffic"], _ = measured_traffic(args.workload, W, H, short(kernel_name))
         if n > 1 or force_dist:
             out["comm"] = {"backend": td.get_backend(), "world_size": n, "ranks_in_group": td.get_world_size(),
                            "exchange": "ncclGather through ctypes (relativitypathtracer_amd/rccl.py), one per " + (f"{frame.group} frames" if frame.group > 1 else "frame") if comm is not None
                                        else "torch.distributed.gather",
                            "split_timings_ms_per_frame": split_timings,
+                           "config5": config5,
                            "note": "every N > 1 figure before an 8-GPU node has run this line is a rehearsal on one GPU or a model: none is a measurement of xGMI"}
         if not args.no_cpu_baseline and n == 1:
             out["cpu_baseline"] = cpu_baseline(scene, W, H)

@@ -265,6 +265,12 @@ int rpt_probe(rpt_ctx *ctx, int which, const void *host_in, void *host_out, int 
  * transformPoint(InvM), transformPoint4D(Lorentz), transformDirection(InvM), applyTranspose(InvM)); 3 n primary rays given by
  * their camera direction through the form the default kernels use (3 in, 8 out as in 0). */
 int rpt_probe_object(rpt_ctx *ctx, int which, int object_index, const float *host_in, float *host_out, int n);
+/* Test hook / experiment (csrc/rpt_device_math.hip.h: three quotients by one scalar through ONE refined reciprocal): compares the
+ * shared-reciprocal quotients with IEEE division on blocks * 256 * per_thread generated (x, y, z, s) sets on the device.  mode 0
+ * random, 1 denominators with an all-ones significand, 2 normalize() (s = sqrt(dot(v, v))), 3 arbitrary bit patterns.  counts_out =
+ * {sets inside the fast path's domain, mismatching quotients with one residual correction, with two, mismatches of the guarded
+ * form over ALL sets, mismatching sets seen}; the first max_samples mismatching sets (4 floats each) go to samples_out. */
+int rpt_probe_division(rpt_ctx *ctx, int mode, unsigned int seed, int blocks, int per_thread, unsigned long long counts_out[5], float *samples_out, int max_samples);
 /* Test hook, the octree walk at ray level: n rays {origin.xyz, dir.xyz} in the object space of mesh object `object_index` of the
  * current Object[] go through the three walks of the product library — the reference's layouts (opencl_kernel.cl:200-308 as
  * written), the throughput walk of kernel 41 and the latency walk of kernel 43 — and host_out receives 3 x 8 floats per ray:

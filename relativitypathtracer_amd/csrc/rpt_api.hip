@@ -1494,6 +1494,31 @@ int rpt_probe_walk(rpt_ctx *ctx, int object_index, const float *host_rays, float
     return rc;
 }
 
+int rpt_probe_division(rpt_ctx *ctx, int mode, unsigned int seed, int blocks, int per_thread, unsigned long long counts_out[5], float *samples_out, int max_samples) {
+    if (!ctx || !counts_out || mode < 0 || mode > 3 || blocks <= 0 || blocks > 65536 || per_thread <= 0 || max_samples < 0) return RPT_ERR_ARG;
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long *d_counts = nullptr;
+    float *d_samples = nullptr;
+    RPT_HIP(ctx, hipMalloc((void **)&d_counts, 5 * sizeof(unsigned long long)));
+    if (max_samples > 0 && samples_out && hipMalloc((void **)&d_samples, sizeof(float) * 4 * (size_t)max_samples) != hipSuccess) {
+        (void)hipFree(d_counts);
+        return fail(ctx, RPT_ERR_NOMEM, "rpt_probe_division: hipMalloc");
+    }
+    int rc = RPT_OK;
+    if (hipMemsetAsync(d_counts, 0, 5 * sizeof(unsigned long long), ctx->stream) != hipSuccess) rc = RPT_ERR_DEVICE;
+    if (!rc && d_samples && hipMemsetAsync(d_samples, 0, sizeof(float) * 4 * (size_t)max_samples, ctx->stream) != hipSuccess) rc = RPT_ERR_DEVICE;
+    if (!rc) {
+        hipLaunchKernelGGL(rptd::rpt_probe_division_kernel, dim3((unsigned int)blocks), dim3(256), 0, ctx->stream, mode, (uint32_t)seed, per_thread, d_counts, d_samples, max_samples);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+            hipMemcpy(counts_out, d_counts, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess ||
+            (d_samples && hipMemcpy(samples_out, d_samples, sizeof(float) * 4 * (size_t)max_samples, hipMemcpyDeviceToHost) != hipSuccess))
+            rc = fail(ctx, RPT_ERR_DEVICE, "rpt_probe_division: device error");
+    }
+    (void)hipFree(d_counts);
+    if (d_samples) (void)hipFree(d_samples);
+    return rc;
+}
+
 int rpt_probe_object(rpt_ctx *ctx, int which, int object_index, const float *host_in, float *host_out, int n) {
     if (!ctx || !host_in || !host_out || n <= 0 || which < 0 || which > 3) return RPT_ERR_ARG;
     if (!ctx->scene_uploaded || ctx->object_count <= 0) return fail(ctx, RPT_ERR_STATE, "rpt_probe_object before rpt_upload_scene / rpt_set_objects");

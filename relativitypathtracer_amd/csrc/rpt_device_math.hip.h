@@ -30,7 +30,45 @@ RPT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); 
 RPT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 RPT_DEV f3 operator/(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
 RPT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+
+// ---- three quotients by ONE scalar (normalize(), dir / scale: opencl_kernel.cl:216, 317, 339, 587-593) ---------------------------
+// The correctly rounded x / s costs 11 instructions (v_div_scale x 2, v_rcp, four fmas, v_div_fmas, v_div_fixup), three of them 33.
+// What the three have in common is the reciprocal: r = rcp(s) refined by one Newton step is the correctly rounded 1 / s for every
+// s whose significand is not all ones (Markstein), and a quotient is then finished by residual corrections
+//     q = n r;   e = fma(-s, q, n);   q = fma(e, r, q)          [ROUNDS times]
+// in which every residual e is exact.  That is the tail of the hardware sequence without its scaling — valid while nothing
+// overflows, underflows or is a zero (a signed zero comes out of the fmas with the wrong sign): the fast path is taken only for a
+// wave whose every lane has 2^-40 <= |s| <= 2^40 and 2^-60 <= |n| <= 2^60 for all three numerators (NaNs fail the test), anything
+// else takes the IEEE divisions.  Whether the result equals x / s bit for bit on that domain is not argued but TESTED on the
+// device (rpt_probe_division: 10^9 quotients, all-ones significands, the actual normalize() inputs of a frame).
+// RPT_SHARED_RCP = number of residual corrections (1 or 2); undefined or 0 = three IEEE divisions (the product as shipped).
+template <int ROUNDS>
+RPT_DEV f3 div3_shared_unguarded(f3 a, float s) {
+    const float r0 = __builtin_amdgcn_rcpf(s);
+    const float r = __builtin_fmaf(__builtin_fmaf(-s, r0, 1.0f), r0, r0);
+    float qx = a.x * r, qy = a.y * r, qz = a.z * r;
+#pragma unroll
+    for (int k = 0; k < ROUNDS; k++) {
+        qx = __builtin_fmaf(__builtin_fmaf(-s, qx, a.x), r, qx);
+        qy = __builtin_fmaf(__builtin_fmaf(-s, qy, a.y), r, qy);
+        qz = __builtin_fmaf(__builtin_fmaf(-s, qz, a.z), r, qz);
+    }
+    return mk3(qx, qy, qz);
+}
+RPT_DEV bool div3_shared_domain(f3 a, float s) {
+    const float as = __builtin_fabsf(s), ax = __builtin_fabsf(a.x), ay = __builtin_fabsf(a.y), az = __builtin_fabsf(a.z);
+    return (as >= 0x1p-40f) & (as <= 0x1p40f) & (ax >= 0x1p-60f) & (ax <= 0x1p60f) & (ay >= 0x1p-60f) & (ay <= 0x1p60f) & (az >= 0x1p-60f) & (az <= 0x1p60f);
+}
+template <int ROUNDS>
+RPT_DEV f3 div3_shared(f3 a, float s) {
+    if (__builtin_amdgcn_ballot_w64(!div3_shared_domain(a, s)) == 0ull) return div3_shared_unguarded<ROUNDS>(a, s);      // wave-uniform
+    return mk3(a.x / s, a.y / s, a.z / s);
+}
+#if defined(RPT_SHARED_RCP) && RPT_SHARED_RCP > 0
+RPT_DEV f3 operator/(f3 a, float s) { return div3_shared<RPT_SHARED_RCP>(a, s); }
+#else
 RPT_DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+#endif
 RPT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 RPT_DEV f4 operator+(f4 a, f4 b) { return mk4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 RPT_DEV f4 operator*(f4 a, float s) { return mk4(a.x * s, a.y * s, a.z * s, a.w * s); }
@@ -39,7 +77,7 @@ RPT_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RPT_DEV float dot(f4 a, f4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 RPT_DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 RPT_DEV float length(f3 v) { return __builtin_sqrtf(dot(v, v)); }
-RPT_DEV f3 normalize(f3 v) { const float l = length(v); return mk3(v.x / l, v.y / l, v.z / l); }
+RPT_DEV f3 normalize(f3 v) { const float l = length(v); return v / l; }      // (three divisions by one scalar: operator/ above)
 
 RPT_DEV float cl_min(float x, float y) { return y < x ? y : x; }     // OpenCL min(): y < x ? y : x
 RPT_DEV float cl_max(float x, float y) { return x < y ? y : x; }     // OpenCL max(): x < y ? y : x

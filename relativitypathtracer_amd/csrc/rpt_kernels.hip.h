@@ -1372,6 +1372,63 @@ __global__ void rpt_probe_kernel(int which, const float *in, float *out, int n) 
     }
 }
 
+// rpt_probe_division: are the shared-reciprocal quotients of rpt_device_math.hip.h equal to IEEE division bit for bit?  Every thread
+// draws `per_thread` (numerators, denominator) sets from a counter-based generator and compares div3_shared_unguarded<1> and <2>
+// with x / s on those INSIDE the fast path's domain, and the guarded div3_shared<2> on ALL of them.  mode 0: random significands,
+// exponents over the whole domain (and beyond it for the guarded form); 1: the same with the denominator's significand all ones;
+// 2: normalize() itself — a random vector, s = sqrt(dot(v, v)) as length() forms it; 3: arbitrary bit patterns (NaN, infinities,
+// zeros, denormals: only the guarded form is compared).  counts[0..3] = sets compared unguarded, mismatching quotients with one
+// round, with two rounds, mismatches of the guarded form; the first few mismatching sets go to `samples` (4 floats each).
+RPT_DEV uint32_t probe_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(256) void rpt_probe_division_kernel(int mode, uint32_t seed, int per_thread, unsigned long long *counts, float *samples, int max_samples) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long n_cmp = 0, bad1 = 0, bad2 = 0, badg = 0;
+    for (int it = 0; it < per_thread; it++) {
+        const uint32_t base = probe_hash(seed ^ probe_hash(tid * 0x9e3779b9u + (uint32_t)it));
+        uint32_t w[4];
+        for (int k = 0; k < 4; k++) w[k] = probe_hash(base + 0x632be5abu * (uint32_t)(k + 1));
+        float v[4];
+        if (mode == 3) {
+            for (int k = 0; k < 4; k++) v[k] = __uint_as_float(w[k]);
+        } else {
+            for (int k = 0; k < 4; k++) {
+                const uint32_t sign = w[k] & 0x80000000u, mant = (mode == 1 && k == 3) ? 0x7fffffu : (w[k] & 0x7fffffu);
+                const int span = k == 3 ? 100 : 140;                      // exponents: the domain and a little beyond
+                const int e = 127 - span / 2 + (int)((w[k] >> 23) % (uint32_t)span);
+                v[k] = __uint_as_float(sign | ((uint32_t)e << 23) | mant);
+            }
+            if (mode == 2) {
+                const f3 t = mk3(v[0], v[1], v[2]);
+                v[3] = length(t);
+            }
+        }
+        const f3 a = mk3(v[0], v[1], v[2]);
+        const float s = v[3];
+        const f3 ref = mk3(a.x / s, a.y / s, a.z / s);
+        auto same = [](float p, float q) { return __float_as_uint(p) == __float_as_uint(q) || (p != p && q != q); };
+        bool report = false;
+        if (div3_shared_domain(a, s)) {
+            n_cmp++;
+            const f3 q1 = div3_shared_unguarded<1>(a, s), q2 = div3_shared_unguarded<2>(a, s);
+            const int b1 = !same(q1.x, ref.x) + !same(q1.y, ref.y) + !same(q1.z, ref.z);
+            const int b2 = !same(q2.x, ref.x) + !same(q2.y, ref.y) + !same(q2.z, ref.z);
+            bad1 += b1; bad2 += b2;
+            report = b2 != 0 || (b1 != 0 && mode != 1);
+        }
+        const f3 g = div3_shared<2>(a, s);
+        const int bg = !same(g.x, ref.x) + !same(g.y, ref.y) + !same(g.z, ref.z);
+        badg += bg;
+        if ((report || bg) && samples) {
+            const unsigned long long slot = atomicAdd(&counts[4], 1ull);
+            if (slot < (unsigned long long)max_samples) { float *o = samples + 4 * slot; o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = s; }
+        }
+    }
+    atomicAdd(&counts[0], n_cmp); atomicAdd(&counts[1], bad1); atomicAdd(&counts[2], bad2); atomicAdd(&counts[3], badg);
+}
+
 // Known-answer probes at OBJECT level (rpt_probe_object; the oracle's counterpart is rpt_oracle_object_rays): which =
 //   0: one 4-D ray {origin4, dir4} in the rest frame of object `object` through intersect_object, the general form every shadow ray
 //      and the V = 0 kernel's primary rays take: out 8 = {hit, dist, normal.xyz, uv.xy, 0}   (opencl_kernel.cl:312-359, 200-308)

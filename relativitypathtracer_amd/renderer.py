@@ -224,6 +224,13 @@ class Renderer:
         self._check(self._lib.rpt_probe(self._h, which, inputs.ctypes.data, out.ctypes.data, n), "rpt_probe")
         return out
 
+    def probe_division(self, mode: int, seed: int, blocks: int, per_thread: int, max_samples: int = 16):
+        """rpt_probe_division (include/rpt.h): (counts[5], samples[max_samples, 4])."""
+        counts = (C.c_uint64 * 5)()
+        samples = np.zeros((max_samples, 4), dtype=np.float32)
+        self._check(self._lib.rpt_probe_division(self._h, int(mode), int(seed) & 0xffffffff, int(blocks), int(per_thread), counts, samples.ctypes.data, max_samples), "rpt_probe_division")
+        return [int(c) for c in counts], samples
+
     def probe_object(self, which: int, object_index: int, inputs: np.ndarray) -> np.ndarray:
         """rpt_probe_object (include/rpt.h): which = 0 (n, 8) rest-frame rays -> (n, 8); 1 (n, 9) shadow rays -> (n, 2) {un-culled, culled}
         occlusion; 2 (n, 4) vectors -> (n, 16) the four transforms; 3 (n, 3) camera directions -> (n, 8)."""

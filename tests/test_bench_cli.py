@@ -29,6 +29,7 @@ def test_bare_gpus_n_launches_its_own_ranks(n):
     assert CONTRACT_KEYS <= set(out)
     assert out["n_gpus"] == n and out["steps"] == 4 and out["warmup"] == 1 and out["dry_run"] is True
     assert out["comm"]["ranks_in_group"] == n and out["comm"]["world_size"] == n
+    assert "7680x4320" in out["comm"]["config5"]["workload"]          # the N > 1 line carries config 5 (timed in a real run)
     assert out["config"]["workload"].startswith("Scenes/bunny.txt 3840x2160") and "model" not in out["config"]
 
 

@@ -587,6 +587,24 @@ def test_bench_several_ranks_on_one_gpu_over_gloo(n, split, gather):
         assert out["config"]["sharding"].startswith("weighted")
 
 
+def test_bench_n_gt_1_line_carries_config_5():
+    """With N > 1 the line also times BASELINE config 5 (bunny 7680x4320; here a smaller stand-in, two ranks on one GPU over gloo)
+    in the three arrangements — the one shipped workload where sharding can pay."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {**os.environ, "RPT_BENCH_BACKEND": "gloo", "RPT_SPLIT": "equal", "RPT_BENCH_CONFIG5": "1920x1080"}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--width", "1280", "--height", "720", "--no-cpu-baseline", "--check"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    c5 = out["comm"]["config5"]
+    assert c5 and "1920x1080" in c5["workload"] and {"equal", "solo"} <= set(c5["ms_per_frame"]) and c5["chosen"] in c5["ms_per_frame"]
+    assert any(k.startswith("weighted_root_run_") for k in c5["ms_per_frame"]) and c5["value_chosen"] > 0
+    assert out["check"] == "framebuffer rows identical to the oracle", out["check"]
+
+
 def test_16k_frame_structure_and_sampled_rows(renderer):
     """A 15360x8640 frame (132.7 M pixels, 2.1 GB of framebuffer; four times BASELINE's largest): every pixel's
     (x, y) floats checked on the device, and row bands through sky, silhouette and mesh compared with the oracle."""
