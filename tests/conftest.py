@@ -67,6 +67,10 @@ REFERENCE_SHOTS = {
     # 2 rad about y (the `p` line's angle/axis; found by tests/golden/fit_reference_camera.py::fit_sphere_rotation) —
     # with exactly that, EVERY pixel of the grab is within 1 LSB.  Pins the textured-sphere (u,v) of
     # opencl_kernel.cl:356-357 (atan2 / asin) and the bilinear fetch on a sphere.
+    # Screenshots/mesh2.png: Scenes/bunny.txt seen by a camera receding along -z with light propagation on.  The light sphere is
+    # reproduced exactly by a one-parameter family of (speed, clock) pairs — this is its slow end; the bunny's pose by none of them
+    # (tests/golden/make_reference_fixtures.py): only the light sphere of this grab is a pin.
+    "mesh2": dict(scene="bunny", v=(0.0, 0.0, -math.tanh(200 / 5000.0)), t=3.07, interval=-1),
     "sphere_stationary": dict(text="TTextures/soccer.jpg\nOs\n p0,0,5,2,0,1,0,2,2,2\n t0\n v0,0,0\nR\n", v=(0.0, 0.0, 0.0), t=0.0, interval=-1),
     # "Moving sphere" (README.md:126-127): the same turned ball at 0.99c (the shipped file says 0.9c; 0.99c, 2 rad and the
     # ball's place along its path — 0.99 x 4.5555 units past the origin, written here as a start at the origin and a clock

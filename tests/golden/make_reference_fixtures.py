@@ -53,6 +53,18 @@ bar; the client area is 2560x1377.
                          similarity of the image plane, the bunny's pose (silhouette IoU 0.94 at scale 1.28).  The crop holds
                          the light sphere.
 
+  mesh2.png, mesh3.png   two more grabs of the bunny scene that the README does not describe.  mesh2: the light sphere sits 5 pixels higher
+                         than in mesh1 and the bunny shows another side.  The sphere is reproduced EXACTLY (0 of its 1 079 pixels off) by
+                         a camera receding along -z with light propagation on — by a whole one-parameter family of such states (from
+                         0.04c after 3.07 s to 0.95c after 7.30 s: the analytic sphere cannot tell them apart) — and the bunny's silhouette
+                         by none of them (IoU 0.67 under the mesh1 similarity, against 0.94 for mesh1), nor by any rotation of the `p` line
+                         about ten axes: the grab's exact scene line is not recoverable, and the model file is missing anyway.  Kept: the
+                         light sphere's crop, as a second exact pin of an analytic object seen from a MOVING camera with light delay.
+                         mesh3: the camera stands next to / inside the bunny (primary rays starting inside the mesh's root box,
+                         opencl_kernel.cl:233-248), no analytic object in view, a model the tree lacks: nothing of it can be pinned; the
+                         regime is tested HIP-against-oracle (tests/test_gpu_parity.py::test_camera_inside_the_mesh_root_box).
+                         (Found by /tmp fits during round 4; the numbers are in DESIGN.md section 3.)
+
 Written per image: an exact stride-4 subsample of the client area (every 4th pixel of every 4th row, no
 filtering) and one full-resolution crop of the part with the most detail.
 """
@@ -87,6 +99,9 @@ for name, crop in CROPS.items():
     if crop:
         y0, y1, x0, x1 = crop
         Image.fromarray(np.ascontiguousarray(im[y0:y1, x0:x1])).save(os.path.join(DST, f"ref_{name}_crop_y{y0}_x{x0}.png"), optimize=True)
+# mesh2.png: the light sphere only (full resolution), see above
+im = np.asarray(Image.open(os.path.join(SRC, "mesh2.png")).convert("RGB"))[TITLE_BAR:]
+Image.fromarray(np.ascontiguousarray(im[290:400, 1200:1360])).save(os.path.join(DST, "ref_mesh2_crop_y290_x1200.png"), optimize=True)
 for gif, frames, stem in (("cubes", (26,), "cubes"), ("ladder_paradox_garage_frame", (60, 100, 140), "ladder"),
                          ("ladder_paradox_ladder_frame", (60, 100, 140), "ladderframe")):
     im = Image.open(os.path.join(SRC, gif + ".gif"))

@@ -15,6 +15,7 @@ image, so the oracle is pinned by what the reference DOES ship o
 2. the per-ray work counts SURVEY.md §8(a) recorded from the reference run during the survey;
 3. committed golden frames of the oracle itself (drift detector).
 """
+import math
 import os
 
 import numpy as np
@@ -134,6 +135,24 @@ def test_reference_screenshot_mesh1_the_headline_scene():
     s.update_objects()
     off = _render_top_down("mesh1", rows=(300, 390), scene=s)[:, 1230:1330]
     assert np.abs(off - _load("ref_mesh1_crop_y300_x1230.png")).max() > 50
+
+
+def test_reference_screenshot_mesh2_light_sphere_from_a_receding_camera():
+    """Screenshots/mesh2.png: the bunny scene from a MOVING camera (receding along -z, light propagation on).  Its light sphere — an
+    analytic object seen with aberration and light delay — is reproduced pixel for pixel (0 of the crop's 17 600 pixels differ) at
+    the state in REFERENCE_SHOTS, and likewise at the fast end of the family of states the sphere cannot tell apart (0.95c after
+    7.301 s: <= 8 pixels).  The bunny of this grab is NOT pinned: no camera state and no rotation of its `p` line reproduces its
+    silhouette with the stand-in model (IoU 0.67), see tests/golden/make_reference_fixtures.py."""
+    ref = _load("ref_mesh2_crop_y290_x1200.png")
+    img = _render_top_down("mesh2", rows=(290, 400))[:, 1200:1360]
+    assert np.abs(img - ref).max() == 0
+    s = Scene.from_file("bunny")
+    s.set_camera((0.0, 0.0, -math.tanh(9400 / 5000.0)), 7.301)
+    s.update_objects()
+    fast = _render_top_down("mesh2", rows=(290, 400), scene=s)[:, 1200:1360]
+    assert (np.abs(fast - ref).max(axis=2) > 1).sum() <= 12
+    rest = _render_top_down("mesh1", rows=(290, 400))[:, 1200:1360]                    # ... and it is not the resting camera's sphere
+    assert (np.abs(rest - ref).max(axis=2) > 1).sum() > 200
 
 
 def test_reference_screenshot_sphere_moving_boosted_textured_sphere():
