@@ -55,6 +55,7 @@ struct Geometry {
     DeviceBuffer vertices, normals, uvs, triangles, octrees, octreeTris, textures;
     DeviceBuffer dnodes, dtris, dlinks;       // derived layouts (rpt_kernels.hip.h)
     DeviceBuffer dfirst;                      // first triangle record of every node's list, by node index (the latency walk)
+    DeviceBuffer dseen;                       // (diagnostics library) per (node, face): {leaf across the face, mask of this leaf's list entries also in that leaf's list}
     DeviceBuffer dgrids;                      // 16^3 cells per octree root: where four child steps from the root end (descend_from_root)
     int grid_roots = 0;
     bool compact_ok = false;                  // derived octree layout usable (children consecutive)
@@ -68,7 +69,7 @@ struct Geometry {
     size_t vertex_count = 0, normal_count = 0, uv_count = 0, triangle_words = 0, octree_count = 0, octree_tri_count = 0;
     ~Geometry() {
         (void)hipSetDevice(device);
-        for (DeviceBuffer *b : {&vertices, &normals, &uvs, &triangles, &octrees, &octreeTris, &textures, &dnodes, &dtris, &dlinks, &dfirst, &dgrids}) release(*b);
+        for (DeviceBuffer *b : {&vertices, &normals, &uvs, &triangles, &octrees, &octreeTris, &textures, &dnodes, &dtris, &dlinks, &dfirst, &dgrids, &dseen}) release(*b);
     }
 };
 
@@ -348,6 +349,28 @@ int build_derived_geometry(rpt_ctx *ctx, const rpt_scene_desc &s) {
             }
         if (int rc = upload(ctx, g.dgrids, grids.data(), grids.size() * sizeof(int32_t))) return rc;
         g.grid_roots = (int)roots;
+    }
+    {   // octree_walk<..., DEDUP>'s table (measurement arms 705 / 717): per leaf and face, the leaf across that face (if the link points
+        // at a leaf) and which of this leaf's first 32 list entries name a triangle that is also in THAT leaf's list
+        std::vector<uint32_t> seen(n * 12, 0u);
+        std::vector<int> sorted_ids;
+        for (size_t k = 0; k < n; k++) {
+            for (int f = 0; f < 6; f++) { seen[(k * 6 + f) * 2] = 0xffffffffu; seen[(k * 6 + f) * 2 + 1] = 0u; }
+            if (nodes[k].link != -1 || nodes[k].leafCount <= 0) continue;
+            for (int f = 0; f < 6; f++) {
+                const int q = nodes[k].nb[f];
+                if (q < 0 || nodes[(size_t)q].link != -1 || nodes[(size_t)q].leafCount <= 0) continue;
+                sorted_ids.clear();
+                for (int t = 0; t < nodes[(size_t)q].leafCount; t++) sorted_ids.push_back(tris[(size_t)nodes[(size_t)q].leafBegin + (size_t)t].tri);
+                std::sort(sorted_ids.begin(), sorted_ids.end());
+                uint32_t mask = 0u;
+                for (int t = 0; t < nodes[k].leafCount && t < 32; t++)
+                    if (std::binary_search(sorted_ids.begin(), sorted_ids.end(), tris[(size_t)nodes[k].leafBegin + (size_t)t].tri)) mask |= 1u << t;
+                seen[(k * 6 + f) * 2] = (uint32_t)q;
+                seen[(k * 6 + f) * 2 + 1] = mask;
+            }
+        }
+        if (int rc = upload(ctx, g.dseen, seen.data(), seen.size() * sizeof(uint32_t))) return rc;
     }
 #endif
     for (size_t k = 0; k < n; k++)          // leafBegin | min(leafCount, 255) << 24: see load_node_rec
@@ -670,6 +693,8 @@ int launch_diagnostic(rpt_ctx *ctx, rptd::KernelArgs &a, dim3 grid, int tiles, i
     case 657: hipLaunchKernelGGL(rptd::rpt_render_kernel_x657, dim3(grid.x * 4, grid.y), dim3(64), 0, ctx->stream, a); break;
     case 669: hipLaunchKernelGGL(rptd::rpt_render_kernel_x669, dim3(grid.x * 4, grid.y), dim3(64), 0, ctx->stream, a); break;
     case 673: hipLaunchKernelGGL(rptd::rpt_render_kernel_x673, dim3(grid.x * 4, grid.y), dim3(64), 0, ctx->stream, a); break;
+    case 705: hipLaunchKernelGGL(rptd::rpt_render_kernel_x705, dim3(grid.x * 4, grid.y), dim3(64), 0, ctx->stream, a); break;      // kernel 41's walk without the repeated triangle tests
+    case 717: hipLaunchKernelGGL(rptd::rpt_render_kernel_x717, dim3(grid.x * 4, grid.y), dim3(64), 0, ctx->stream, a); break;      // kernel 43's walk likewise
     RPT_LAUNCH_X(689) RPT_LAUNCH_X(701)          // kernel 41's / 43's walk launched four waves per workgroup (what the product did before)
     case 2573: hipLaunchKernelGGL(rptd::rpt_render_kernel_x573_w4, grid, dim3(256), 0, ctx->stream, a); break;      // the latency kernel at 4 waves per SIMD (128 VGPRs, no scratch)
     case 7:
@@ -703,6 +728,7 @@ int launch(rpt_ctx *ctx) {
     a.links = (const int *)ctx->geo->dlinks.ptr;
     a.first_tris = (const rptd::DTri *)ctx->geo->dfirst.ptr;
     a.root_grids = (const int *)ctx->geo->dgrids.ptr;       // (null and 0 in the product library)
+    a.seen_before = (const uint2 *)ctx->geo->dseen.ptr;     // (likewise)
     a.grid_roots = ctx->geo->grid_roots;
     a.top_count = ctx->geo->top_count;
     a.dobjs = (const rptd::DObj *)((const char *)ctx->objects.ptr + (size_t)ctx->object_count * sizeof(rpt_object));
@@ -1449,6 +1475,7 @@ static void probe_kernel_args(rpt_ctx *ctx, rptd::KernelArgs &a) {
     a.links = (const int *)ctx->geo->dlinks.ptr;
     a.first_tris = (const rptd::DTri *)ctx->geo->dfirst.ptr;
     a.root_grids = (const int *)ctx->geo->dgrids.ptr;       // (null and 0 in the product library)
+    a.seen_before = (const uint2 *)ctx->geo->dseen.ptr;
     a.grid_roots = ctx->geo->grid_roots;
     a.top_count = ctx->geo->top_count;
     a.dobjs = (const rptd::DObj *)((const char *)ctx->objects.ptr + (size_t)ctx->object_count * sizeof(rpt_object));

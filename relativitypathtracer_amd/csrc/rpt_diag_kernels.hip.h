@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_r02walk_first_w5(const KernelArgs a) { render_pixel_body<123>(a); } // 143: round 2's walk, mesh band first
 #define RPT_X_KERNEL(N) __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_x##N(const KernelArgs a) { render_pixel_body<N>(a); }
 #define RPT_X1_KERNEL(N) __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void rpt_render_kernel_x##N(const KernelArgs a) { render_pixel_body<N>(a); }
-RPT_X1_KERNEL(657) RPT_X1_KERNEL(669) RPT_X1_KERNEL(673)      /* one wave per workgroup, like the product kernels they are compared with */
+RPT_X1_KERNEL(657) RPT_X1_KERNEL(669) RPT_X1_KERNEL(673) RPT_X1_KERNEL(705) RPT_X1_KERNEL(717)      /* one wave per workgroup, like the product kernels they are compared with */
 #define RPT_XW_KERNEL(N, W) __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) void rpt_render_kernel_x##N##_w##W(const KernelArgs a) { render_pixel_body<N>(a); }
 RPT_XW_KERNEL(257, 6) RPT_XW_KERNEL(257, 4) RPT_XW_KERNEL(263, 4) RPT_XW_KERNEL(259, 4) RPT_XW_KERNEL(573, 4)
 RPT_X_KERNEL(256) RPT_X_KERNEL(257) RPT_X_KERNEL(259) RPT_X_KERNEL(261) RPT_X_KERNEL(263) RPT_X_KERNEL(265) RPT_X_KERNEL(269)

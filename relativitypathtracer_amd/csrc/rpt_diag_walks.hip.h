@@ -487,6 +487,8 @@ RPT_DEV bool diag_walk(const KernelArgs &a, const rpt_object &obj, int root, con
     if (V == 673) return octree_walk<false, false, true, false, true, 2>(a, obj, root, newRay, world_origin, world_dirlen, hit);        // likewise with ONE lane's vector loads + readfirstlane (UNIFORM = 2)
     if (V == 657) return octree_walk<false, false, true, false, true, 1>(a, obj, root, newRay, world_origin, world_dirlen, hit);     // kernel 41's walk + UNIFORM (scalar loads where the wave stands in one node)
     if (V == 669) return octree_walk<true, true, false, false, true, 1>(a, obj, root, newRay, world_origin, world_dirlen, hit);      // kernel 43's walk + UNIFORM, mesh band first
+    if (V == 705) return octree_walk<false, false, true, false, true, 0, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);      // kernel 41's walk + DEDUP: list entries tested in the previous leaf are neither loaded nor tested
+    if (V == 717) return octree_walk<true, true, false, false, true, 0, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);       // kernel 43's walk + DEDUP (records are prefetched: the arithmetic only), mesh band first
     if (V == 689) return octree_walk<false, false, true, false, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);     // kernel 41's walk launched FOUR waves per workgroup (a 32 x 8 strip), as every measurement arm is and the product was
     if (V == 701) return octree_walk<true, true, false, false, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);      // kernel 43's walk, likewise, mesh band first
     if (V == 621) return octree_walk_nbrec<true, true>(a, obj, root, newRay, world_origin, world_dirlen, hit);      // 541 + a leaf's first triangle with its node: a whole step's data in one round trip

@@ -111,6 +111,7 @@ struct KernelArgs {
     const DObj *dobjs;
     const int *links;               // DNode::link of every node again, 4 B apart: what a descent reads per level
     const DTri *first_tris;         // per node: the first triangle record of its leaf list again, addressable by the NODE's index
+    const uint2 *seen_before;       // (diagnostics library: arms 705 / 717) per (node, entry face): {the leaf across that face, bit mask of this leaf's first 32 list entries that are also in THAT leaf's list}; product: null
     const int *root_grids;          // (diagnostics library: arms 593 / 605) per octree root, 16^3 cells -> node | level << 24 | leaf << 28; product: null
     int grid_roots;
     int top_count;                  // nodes [0, top_count) are the forest's top levels (whole levels, <= RPT_TOP_MAX)
@@ -577,10 +578,22 @@ RPT_DEV TriRec load_tri_rec_leader(const KernelArgs &a, int k) {
 
 #endif
 
-template <bool PIPELINE, bool FIRST, bool PACKED_COUNT = true, bool ROOT_GRID = false, bool LATE_ID = false, int UNIFORM = 0>
+// DEDUP (measurement arms 705 / 717): a triangle that overlaps k leaves is in all k lists, and one walk tests it up
+// to k times (23.8 % of the bunny's triangle tests, 28.4 % of the pear's: profiles/r04_repeated_triangle_tests.txt).  A repeat can
+// never change the walk's state — the test's outcome depends on the ray and the triangle only, and the update rule
+// 0 <= dist < hit.dist (opencl_kernel.cl:270) with a non-increasing hit.dist makes a second application a no-op (accepted before:
+// now dist == hit.dist or larger, not "<"; rejected before: rejected again; NaN: false both times).  Skipped are list entries whose
+// triangle is ALSO IN THE LIST OF THE LEAF THIS WALK VISITED IMMEDIATELY BEFORE: the host marks, per leaf and face, which of the
+// leaf's first 32 entries are in the list of the leaf across that face (seen_before[node * 6 + face] = {that leaf, mask}); the lane
+// uses the mask of the face it entered through (the previous step's exit face, flipped) only if the leaf recorded there IS the
+// leaf it came from — an integer compare, nothing geometric is assumed — and every entry of that leaf's list was either tested
+// in the previous step or skipped there for the same reason (induction over the steps).  The record's address is known with
+// the node's: its load travels with the node record and does not lengthen the chain.
+template <bool PIPELINE, bool FIRST, bool PACKED_COUNT = true, bool ROOT_GRID = false, bool LATE_ID = false, int UNIFORM = 0, bool DEDUP = false>
 RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, const Ray &newRay, f3 world_origin,
                          float world_dirlen, Hit &hit) {
     int curr = root;
+    int prev_leaf = -1, entry_face = 0;
     bool uni = false;
     NodeRec rec = load_node_rec<PACKED_COUNT>(a, curr);
     f2 d;
@@ -618,6 +631,12 @@ RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, c
         }
         int i = __float_as_int(rec.hi.w) & RPT_NODE_BEGIN_MASK;
         const int trisEnd = i + rec.count;
+        unsigned int seen = 0u;
+        if (DEDUP && prev_leaf >= 0) {
+            const uint2 e = a.seen_before[(size_t)curr * 6 + entry_face];
+            seen = (int)e.x == prev_leaf ? e.y : 0u;
+        }
+        const int listBegin = i;
         farSide = getOppositeBoxSide(plan, uv);             // the way out, before the triangles
         const int next = a.dnodes[curr].nb[farSide];
         if (UNIFORM && uni) {          // one list for the whole wave: records through the scalar cache
@@ -631,15 +650,21 @@ RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, c
                     TriRec nxt = cur;
                     if (i + 1 < trisEnd) nxt = load_tri_rec<LATE_ID>(a, i + 1);
                     if (LATE_ID) cur.tri = i;
-                    test_tri_rec(cur, newRay, hit, hitTri, didHit);
+                    if (!(DEDUP && i - listBegin < 32 && ((seen >> (i - listBegin)) & 1u))) test_tri_rec(cur, newRay, hit, hitTri, didHit);     // (the record was asked for an iteration ago: only the arithmetic is saved here)
                     cur = nxt;
                 }
+            }
+        } else if (DEDUP) {
+            for (; i < trisEnd; i++) {
+                if (i - listBegin < 32 && ((seen >> (i - listBegin)) & 1u)) continue;                    // tested in the previous leaf: neither loaded nor tested
+                test_tri_rec(load_tri_rec<LATE_ID>(a, i), newRay, hit, hitTri, didHit);
             }
         } else {
             for (; i < trisEnd; i++) test_tri_rec(load_tri_rec<LATE_ID>(a, i), newRay, hit, hitTri, didHit);
         }
         uv = nmin + uv * (nmax - nmin);
         if (exit_is_past_hit(uv - newRay.origin, hit.dist, didHit) || next == -1) break;
+        if (DEDUP) { prev_leaf = curr; entry_face = farSide ^ 1; }      // sides 0/1 = -z/+z, 2/3 = -x/+x, 4/5 = -y/+y: the face entered is the face left, flipped
         curr = next;
         rec = load_node_rec_u<PACKED_COUNT, UNIFORM>(a, curr, uni);
         if (FIRST) first = load_first_tri<LATE_ID>(a, curr);
@@ -1088,7 +1113,7 @@ RPT_DEV unsigned long long wave_object_mask(const KernelArgs &a, int tile_x0, in
 
 template <int V> RPT_DEV constexpr bool culled_variant() { return V >= 20; }
 template <int V> RPT_DEV constexpr bool zorder_lanes() { return V == 641 || V == 653; }
-template <int V> RPT_DEV constexpr bool one_wave_workgroups() { return V == 0 || V == 1 || V == 20 || V == 23 || V == 24 || V == 657 || V == 669 || V == 673; }     // the product kernels (+ three arms re-measured that way)
+template <int V> RPT_DEV constexpr bool one_wave_workgroups() { return V == 0 || V == 1 || V == 20 || V == 23 || V == 24 || V == 657 || V == 669 || V == 673 || V == 705 || V == 717; }     // the product kernels (+ three arms re-measured that way)
 template <int V> RPT_DEV constexpr bool band_first_variant() { return V == 23 || V == 123 || (V >= 256 && V < 1000 && (V & 8)); }
 
 // ---------------------------------------------------------------------------------------------

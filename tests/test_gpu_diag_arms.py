@@ -16,6 +16,8 @@ renders something else would be worthless.  So they are held to the product's ba
   593, 605  the 16^3 root table (descend_from_root) in kernel 41's / 43's walk
   641, 653  the lanes of a wave along the Z curve through its tile
   657, 669, 673   records read once per wave where the wave stands in one node: through the scalar cache / by one lane + readfirstlane
+  705, 717  round 4: kernel 41's / 43's walk WITHOUT the repeated triangle tests (list entries whose triangle was in the previous
+            leaf's list are skipped: exact, see octree_walk's DEDUP in csrc/rpt_kernels.hip.h)
 """
 import numpy as np
 import pytest
@@ -25,7 +27,7 @@ from conftest import load_config
 
 pytestmark = pytest.mark.gpu
 
-ARMS = [26, 40, 42, 141, 143, 60, 61, 62, 63, 256, 257, 259, 261, 263, 265, 269, 273, 277, 285, 305, 317, 337, 349, 401, 1257, 2257, 2259, 2263, 529, 541, 561, 573, 589, 593, 605, 621, 625, 637, 641, 653, 657, 669, 673, 689, 701, 2573]
+ARMS = [26, 40, 42, 141, 143, 60, 61, 62, 63, 256, 257, 259, 261, 263, 265, 269, 273, 277, 285, 305, 317, 337, 349, 401, 1257, 2257, 2259, 2263, 529, 541, 561, 573, 589, 593, 605, 621, 625, 637, 641, 653, 657, 669, 673, 689, 701, 2573, 705, 717]
 SCENES = {"bunny": (480, 270), "shadows": (480, 270), "arch": (480, 270), "cubes": (320, 184), "soccer": (320, 184), "cube": (333, 77)}
 
 
