@@ -18,16 +18,18 @@ def main(tags):
         for suf in ("_pmc_summary.json", "_kernel_stats.csv"):
             shutil.copy(os.path.join(src, t + suf), os.path.join(ROOT, "profiles", t + suf))
         d = json.load(open(os.path.join(ROOT, "profiles", t + "_pmc_summary.json")))
-        r = d["render"]
+        for name, r in d["kernels"].items():          # one block per kernel (tools/pmc_summary.py)
+            if not name.startswith("rpt_render_kernel"):
+                continue
 
-        def g(c):
-            return r.get(c, {}).get("mean", 0.0)
-        wc = max(g("SQ_WAVE_CYCLES"), 1.0)
-        print(f"{t}  lib {d['build']['librpt_hip_sha256'][:10]}  | {g('SQ_INSTS_VALU') / 1e6:.1f} M | "
-              f"{g('SQ_THREAD_CYCLES_VALU') / max(g('SQ_INSTS_VALU'), 1):.0f} of 64 | "
-              f"{100 * g('SQ_WAIT_ANY') / wc:.0f} % / {100 * g('SQ_WAIT_INST_ANY') / wc:.0f} % / {100 * g('SQ_ACTIVE_INST_ANY') / wc:.0f} % | "
-              f"{100 * (1 - g('TCP_TCC_READ_REQ_sum') / max(g('TCP_TOTAL_CACHE_ACCESSES_sum'), 1)):.1f} % | {d['derived']['l2_hit_rate_render'] or 0:.2f} | "
-              f"{g('WRITE_SIZE') * 1024 / 1e6:.1f} / {g('FETCH_SIZE') * 2048 / 1e6:.1f} |   wave residency {wc * 4 / 5120 / 2.4e9 * 1e3:.3f} ms")
+            def g(c, r=r):
+                return r.get(c, {}).get("mean", 0.0)
+            wc = max(g("SQ_WAVE_CYCLES"), 1.0)
+            print(f"{t}  {name}  lib {d['build']['librpt_hip_sha256'][:10]}  | {g('SQ_INSTS_VALU') / 1e6:.1f} M | "
+                  f"{g('SQ_THREAD_CYCLES_VALU') / max(g('SQ_INSTS_VALU'), 1):.0f} of 64 | "
+                  f"{100 * g('SQ_WAIT_ANY') / wc:.0f} % / {100 * g('SQ_WAIT_INST_ANY') / wc:.0f} % / {100 * g('SQ_ACTIVE_INST_ANY') / wc:.0f} % | "
+                  f"{100 * (1 - g('TCP_TCC_READ_REQ_sum') / max(g('TCP_TOTAL_CACHE_ACCESSES_sum'), 1)):.1f} % | {r['derived']['l2_hit_rate'] or 0:.2f} | "
+                  f"{g('WRITE_SIZE') * 1024 / 1e6:.1f} / {g('FETCH_SIZE') * 2048 / 1e6:.1f} |   launches {int(r.get('SQ_WAVES', {}).get('launches', 0))}")
         for line in open(os.path.join(ROOT, "profiles", t + "_kernel_stats.csv")).read().splitlines()[1:3]:
             print("     ", line[:130])
 

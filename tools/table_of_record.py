@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-rnd = args[0] if args else "r03"
+rnd = args[0] if args else "r04"
 out_rows, counter_rows, hashes = [], [], set()
 ROWS = [("**bunny 3840×2160 (the metric)**", "bunny_3840x2160"), ("bunny 1920×1080 (config 3)", "bunny_1920x1080"),
         ("shadows 3840×2160, t = 16 (config 4)", "shadows_3840x2160"), ("arch 1920×1080, v = 0.95c (config 2)", "arch_1920x1080"),
@@ -29,7 +29,7 @@ def rocprof_blocking_ms(key):
         if len(row) > 3 and "rpt_render_kernel" in row[0]:
             names[row[0]] = float(row[3]) / 1e6
     first = [v for k, v in names.items() if "ballot_first" in k]
-    return first[0] if first and len(names) > 1 else None
+    return first[0] if first and len([k for k in names if "ballot" in k or "analytic" in k]) > 1 else None
 
 
 def sp(x):
@@ -57,24 +57,32 @@ for line in open(os.path.join(ROOT, "profiles", f"{rnd}_configs_default.txt")):
 COUNTERS = [("bunny 4K", "bunny_3840x2160", ""), ("bunny 1080p", "bunny_1920x1080", ""), ("shadows 4K", "shadows_3840x2160", ""),
             ("arch 1080p", "arch_1920x1080", ""), ("cube 640×480", "cube_640x480", ""), ("bunny 8K", "bunny_7680x4320", ""),
             ("cubes 4K (34 textured cubes)", "cubes_3840x2160", " (the fetch is the texture pool)")]
+KERNEL_ROWS = [("rpt_render_kernel_ballot_w5", "kernel 41, frames in flight"), ("rpt_render_kernel_ballot_first_w5", "kernel 43"),
+               ("rpt_render_kernel_analytic_w8", "kernel 44, both regimes")]
 for label, key, note in COUNTERS:
     path = os.path.join(ROOT, "profiles", f"{rnd}_{key}_pmc_summary.json")
     if not os.path.exists(path):
         continue
     d = json.load(open(path))
     hashes.add(d["build"]["librpt_hip_sha256"])
-    r = d["render"]
-
-    def g(c):
-        return r.get(c, {}).get("mean", 0.0)
-    wc = max(g("SQ_WAVE_CYCLES"), 1.0)
-    lanes = g("SQ_THREAD_CYCLES_VALU") / max(g("SQ_INSTS_VALU"), 1)
-    lanes_s = f"{min(lanes, 64):.0f} of 64" + (f" (the ratio reads {lanes:.0f}: instructions that issue over eight cycles count twice)" if lanes > 64.5 else "")
     alg = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_bench_{key}.json")))["roofline"]["algorithmic_bytes_per_launch"] / 1e6
-    counter_rows.append(f"| {label} | {g('SQ_INSTS_VALU') / 1e6:.1f} M | {lanes_s} | "
-                        f"{100 * g('SQ_WAIT_ANY') / wc:.0f} % / {100 * g('SQ_WAIT_INST_ANY') / wc:.0f} % / {100 * g('SQ_ACTIVE_INST_ANY') / wc:.0f} % | "
-                        f"{100 * (1 - g('TCP_TCC_READ_REQ_sum') / max(g('TCP_TOTAL_CACHE_ACCESSES_sum'), 1)):.1f} % | {d['derived']['l2_hit_rate_render'] or 0:.2f} | "
-                        f"{g('WRITE_SIZE') * 1024 / 1e6:.1f} / {g('FETCH_SIZE') * 2048 / 1e6:.1f} vs {alg:.1f}{note} |")
+    blocks = d["kernels"]
+    for kname, regime in KERNEL_ROWS:
+        if kname not in blocks:
+            continue
+        r = blocks[kname]
+        if kname.endswith("first_w5"):
+            regime = "kernel 43, one at a time" if "rpt_render_kernel_ballot_w5" in blocks else "kernel 43, in flight AND one at a time (frame <= 3 Mpx)"
+
+        def g(c, r=r):
+            return r.get(c, {}).get("mean", 0.0)
+        wc = max(g("SQ_WAVE_CYCLES"), 1.0)
+        lanes = g("SQ_THREAD_CYCLES_VALU") / max(g("SQ_INSTS_VALU"), 1)
+        lanes_s = f"{min(lanes, 64):.0f} of 64" + (f" (the ratio reads {lanes:.0f}: instructions that issue over eight cycles count twice)" if lanes > 64.5 else "")
+        counter_rows.append(f"| {label} — {regime} ({int(r.get('SQ_WAVES', {}).get('launches', 0))} launches) | {g('SQ_INSTS_VALU') / 1e6:.1f} M | {lanes_s} | "
+                            f"{100 * g('SQ_WAIT_ANY') / wc:.0f} % / {100 * g('SQ_WAIT_INST_ANY') / wc:.0f} % / {100 * g('SQ_ACTIVE_INST_ANY') / wc:.0f} % | "
+                            f"{100 * (1 - g('TCP_TCC_READ_REQ_sum') / max(g('TCP_TOTAL_CACHE_ACCESSES_sum'), 1)):.1f} % | {r['derived']['l2_hit_rate'] or 0:.2f} | "
+                            f"{g('WRITE_SIZE') * 1024 / 1e6:.1f} / {g('FETCH_SIZE') * 2048 / 1e6:.1f} vs {alg:.1f}{note} |")
 print("\n".join(out_rows))
 print()
 print("\n".join(counter_rows))
