@@ -385,25 +385,31 @@ def main():
             rr._check(rr._lib.rpt_timing_begin(rr._h, steps), "rpt_timing_begin")
         barrier()
         t0 = time.perf_counter()
-        nb = min(5, steps)
-        marks, stamps = {(steps * (b + 1)) // nb for b in range(nb - 1)}, [t0]       # batch boundaries INSIDE the one timed region
-        for k in range(steps):
+        for _ in range(steps):
             step()
-            if k + 1 in marks:
-                stamps.append(time.perf_counter())        # (no sync: a slot is reused only when its frame is done, so in steady state frames are submitted at the pace they finish)
         submit = time.perf_counter() - t0
         barrier()
         wall = time.perf_counter() - t0
-        stamps.append(t0 + wall)
-        edges = [0] + sorted(marks) + [steps]
-        batch_ms[:] = [(stamps[b + 1] - stamps[b]) / max(edges[b + 1] - edges[b], 1) * 1e3 for b in range(len(stamps) - 1)]
         if rank == 0 and os.environ.get("RPT_BENCH_VERBOSE") == "1":
             print(f"[bench] host submission {submit / steps * 1e3:.4f} ms/step, wall {wall / steps * 1e3:.4f} ms/step", file=sys.stderr)
-        launches = []
+        # every launch's span on the device's own clock (HIP events; one base event for all frame slots): durations for the roofline, and
+        # the region cut into fifths BY COMPLETION TIME for a figure that does not hang on the ramp of a 2-ms region (the host runs
+        # ahead of the device — it had submitted all twenty steps of the driver's run before the third frame finished — so host time
+        # stamps at submission say nothing)
+        launches, ends, first_begin = [], [], None
         for rr in renderers:
-            launches += end_timing(rr, steps)
-        if rank == 0 and os.environ.get("RPT_BENCH_VERBOSE") == "1":
-            print("[bench] launch durations, ms, per slot in submission order: " + " ".join(f"{x:.3f}" for x in launches), file=sys.stderr)
+            b, e, nfr = (C.c_float * steps)(), (C.c_float * steps)(), C.c_int()
+            rr._check(rr._lib.rpt_timing_end_spans(rr._h, renderers[0]._h, b, e, steps, C.byref(nfr)), "rpt_timing_end_spans")
+            for k in range(nfr.value):
+                launches.append(e[k] - b[k])
+                ends.append(e[k])
+                first_begin = b[k] if first_begin is None else min(first_begin, b[k])
+        ends.sort()
+        batch_ms[:] = []
+        if len(ends) >= 5:
+            cuts = [first_begin] + [ends[(len(ends) * (q + 1)) // 5 - 1] for q in range(5)]
+            sizes = [(len(ends) * (q + 1)) // 5 - (len(ends) * q) // 5 for q in range(5)]
+            batch_ms[:] = [(cuts[q + 1] - cuts[q]) / max(sizes[q], 1) for q in range(5)]
         return wall, launches
 
     for _ in range(max(args.warmup, 0)):
@@ -518,8 +524,8 @@ def main():
                       else f"Mrays/s (primary rays) on Scenes/{scene_name}.txt at {W}x{H}",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
-            # the same region cut into fifths by host time stamps at submission (no extra synchronisation): the median fifth is what a
-            # longer run converges to — a 20-step region is 2 ms long and starts on an idle device, its first fifth carries the ramp
+            # the same region cut into fifths by the COMPLETION times of its launches (HIP events, one clock for all frame slots): the
+            # median fifth is what a longer run converges to — a 20-step region is 2 ms long and starts on an idle device
             "ms_per_step_median_of_batches": (lambda v: round(sorted(v)[len(v) // 2], 4) if v else None)(headline_batches),
             "ms_per_step_batches": [round(x, 4) for x in headline_batches],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

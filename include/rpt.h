@@ -204,6 +204,10 @@ int rpt_timing_begin(rpt_ctx *ctx, int max_frames);
 int rpt_timing_end(rpt_ctx *ctx, float *total_ms, int *frames);
 /* The same, returning every frame's launch duration (up to `capacity`) instead of their sum. */
 int rpt_timing_end_frames(rpt_ctx *ctx, float *per_frame_ms, int capacity, int *frames);
+/* The same region as SPANS: when each timed launch began and ended on the device, in ms after the FIRST timed launch of `base`
+ * began (base: any context of the same device whose timing region started with this one's — frames in flight run on several
+ * contexts, their spans share one clock this way).  Ends the region like rpt_timing_end_frames. */
+int rpt_timing_end_spans(rpt_ctx *ctx, const rpt_ctx *base, float *begin_ms, float *end_ms, int capacity, int *frames);
 
 /* Root side of the multi-GPU exchange: expand `n_ranks` gathered colour planes (rank r's plane at
  * planes + r*plane_stride_bytes) into the 16 B/pixel framebuffer `out16` (x, y, packed colour). */

@@ -140,6 +140,7 @@ HIP_SYMBOLS = {
     "rpt_last_variant": (C.c_int, [C.c_void_p]),
     "rpt_set_msaa": (C.c_int, [C.c_void_p, C.c_int]),
     "rpt_probe_walk": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "rpt_timing_end_spans": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),
     "rpt_probe_division": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_void_p, C.c_int]),
     "rpt_probe_object": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "rpt_render": (C.c_int, [C.c_void_p]),

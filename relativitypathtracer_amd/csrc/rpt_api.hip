@@ -36,7 +36,7 @@ extern "C" int rpt_launch_relaxed_kernel(int waves_per_simd, const void *args, s
 #define RPT_HOST_MARK(K) do { } while (0)
 #endif
 #define RPT_GRID_ROOTS_MAX 64     /* octree roots that get a descend_from_root table (16 KB each) */
-#define RPT_RECT_BATCH_MIN 8      /* screen bounds to recompute in one rpt_set_objects before the helper threads are asked (rpt_workers.hpp) */
+#define RPT_RECT_BATCH_MIN 3      /* screen bounds to recompute in one rpt_set_objects before the helper threads are asked (rpt_workers.hpp); 8 until the bounds were proven as well (round 4: twice the work per object) */
 
 namespace {
 
@@ -1270,6 +1270,23 @@ int rpt_timing_end_frames(rpt_ctx *ctx, float *per_frame_ms, int capacity, int *
     for (int i = 0; i < n; i++) {
         RPT_HIP(ctx, hipEventSynchronize(ctx->timing_events[2 * i + 1]));
         RPT_HIP(ctx, hipEventElapsedTime(&per_frame_ms[i], ctx->timing_events[2 * i], ctx->timing_events[2 * i + 1]));
+    }
+    *frames = n;
+    ctx->timing_frames = -1;
+    return RPT_OK;
+}
+
+int rpt_timing_end_spans(rpt_ctx *ctx, const rpt_ctx *base, float *begin_ms, float *end_ms, int capacity, int *frames) {
+    if (!ctx || !base || !begin_ms || !end_ms || capacity < 0 || !frames) return RPT_ERR_ARG;
+    if (ctx->timing_frames < 0) return fail(ctx, RPT_ERR_STATE, "rpt_timing_end_spans without rpt_timing_begin");
+    if (base->timing_events.empty() || base->device != ctx->device) return fail(ctx, RPT_ERR_ARG, "rpt_timing_end_spans: the base context has no timing events on this device");
+    RPT_HIP(ctx, hipSetDevice(ctx->device));
+    const int n = ctx->timing_frames < capacity ? ctx->timing_frames : capacity;
+    RPT_HIP(ctx, hipEventSynchronize(base->timing_events[0]));
+    for (int i = 0; i < n; i++) {
+        RPT_HIP(ctx, hipEventSynchronize(ctx->timing_events[2 * i + 1]));
+        RPT_HIP(ctx, hipEventElapsedTime(&begin_ms[i], base->timing_events[0], ctx->timing_events[2 * i]));
+        RPT_HIP(ctx, hipEventElapsedTime(&end_ms[i], base->timing_events[0], ctx->timing_events[2 * i + 1]));
     }
     *frames = n;
     ctx->timing_frames = -1;

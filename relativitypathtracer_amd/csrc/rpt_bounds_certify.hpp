@@ -358,12 +358,6 @@ inline bool segment_separable(Problem &p, double ua, double va, double ub, doubl
         generator(p, s1, ua, va, G[ng++]);
         generator(p, s1, ub, vb, G[ng++]);
     }
-    {   // an exact ray through the segment's midpoint that meets B': nothing to certify here (and no halving will help)
-        const double mu = 0.5 * (ua + ub), mv = 0.5 * (va + vb);
-        double g[3];
-        generator(p, p.interval * std::sqrt(mu * mu + mv * mv + 0.25), mu, mv, g);
-        if (ray_meets(p, g, 1.0)) { boundary_hit = true; return false; }
-    }
     double E[3];
     for (int i = 0; i < 3; i++) E[i] = 2.0 * dmax * p.err[i];
     // scales that make the two point sets comparable for the minimum-norm iteration (they do not enter the check)
@@ -396,11 +390,16 @@ inline bool segment_separable(Problem &p, double ua, double va, double ub, doubl
     // but needle-thin configurations (a fan and a shape that both subtend 1e-4 rad and pass 1e-6 rad from each other put the hull
     // within 1e-6 of the origin between points of norm 1: the iterate's DIRECTION is then lost to rounding).
     Simplex S;
-    for (int i = 0; i < 3; i++) S.x[0][i] = cv[i] * ics;      // a point of the hull to start from: the shape's centre
-    S.n = 1;
+    for (int i = 0; i < 3; i++) { S.x[0][i] = cv[i] * ics; S.x[1][i] = 0.0; }      // two points of the hull to start from: the shape's centre ...
+    for (int k = 0; k < ng; k++) for (int i = 0; i < 3; i++) S.x[1][i] -= G[k][i] * igs / ng;      // ... and the fan's mean direction, reversed
+    S.n = 2;
     double n[3];
+    bool enclosed = false;
     for (int it = 0; it < GJK_STEPS; it++) {
-        if (!closest_on_simplex(S, n)) return false;          // 0 inside the hull: not separable
+#ifdef RPT_CERT_COUNT
+        g_iters3++;
+#endif
+        if (!closest_on_simplex(S, n)) { enclosed = true; break; }          // 0 inside the hull: not separable by a plane through o
         const double nn = dot3(n, n);
         if (!(nn > 1.0e-26) || !std::isfinite(nn)) break;
         if (check(n)) return true;
@@ -419,11 +418,21 @@ inline bool segment_separable(Problem &p, double ua, double va, double ub, doubl
         for (int i = 0; i < 3; i++) S.x[S.n][i] = x[i];
         S.n++;
     }
+    {   // an exact ray through the segment's midpoint that meets B': nothing to certify here, and no halving will help
+        const double mu = 0.5 * (ua + ub), mv = 0.5 * (va + vb);
+        double g[3];
+        generator(p, p.interval * std::sqrt(mu * mu + mv * mv + 0.25), mu, mv, g);
+        if (ray_meets(p, g, 1.0)) { boundary_hit = true; return false; }
+    }
+    if (enclosed) return false;
     // Stage 2 — the same question on the plane: seen from o along the axis to the shape's centre, directions with a positive
     // component along the axis are points y = (x . e1, x . e2) / (x . axis) of a plane, planes through o are lines, the fan and the
     // shape are two convex sets of size ~ their angular size, and GJK on their Minkowski difference is well conditioned at any
     // scale.  A separating line m . y = tau gives the normal n = m1 e1 + m2 e2 - tau axis, which goes through the same check.
     {
+#ifdef RPT_CERT_COUNT
+        g_stage2++;
+#endif
         double ax[3] = {cv[0] * ics, cv[1] * ics, cv[2] * ics}, e1[3], e2[3];
         const double helper[3] = {std::fabs(ax[0]) < 0.6 ? 1.0 : 0.0, std::fabs(ax[0]) < 0.6 ? 0.0 : 1.0, 0.0};
         cross3(ax, helper, e1);

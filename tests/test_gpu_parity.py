@@ -134,6 +134,21 @@ def test_camera_inside_the_mesh_root_box(renderer):
     assert inside_seen >= 1
 
 
+def test_frames_wider_than_the_proven_window_render_unculled(renderer):
+    """The screen bounds are proven for the window |u| <= 2, |v| <= 1/2 (csrc/rpt_bounds_certify.hpp): every pixel of a frame of at
+    most 4 : 1.  A wider frame has pixels outside it, and launch() gives it the un-culled kernel — same pixels as the oracle."""
+    scene = load_config("shadows")
+    for (W, H, kernels) in ((1600, 400, (43,)), (1608, 400, (3,)), (2000, 250, (3,)), (800, 200, (43,))):
+        px, rgb = _render_gpu(renderer, scene, W, H, 0)
+        assert renderer.last_variant() in kernels, (W, H, renderer.last_variant())
+        opx, orgb, _ = oracle_ffi.render(scene, W, H)
+        assert np.array_equal(px["rgba"], opx["rgba"]) and np.array_equal(rgb.view(np.uint32), orgb.view(np.uint32)), (W, H)
+        for variant in (41, 43):          # asked for explicitly on a frame they are not proven for: the un-culled kernel all the same
+            _render_gpu(renderer, scene, W, H, variant)
+            assert renderer.last_variant() == (variant if kernels != (3,) else 3), (W, H, variant, renderer.last_variant())
+    renderer.set_variant(0)
+
+
 def test_odd_resolution_guard(renderer):
     """Width/height that are not multiples of the 32x8 strip: the reference has no bounds guard."""
     scene = load_config("shadows")
