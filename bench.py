@@ -107,6 +107,26 @@ def host_cpus():
     return len(allowed), (len(cores) or None)
 
 
+def cpu_quota():
+    """CPUs' worth of run time the container's cgroup grants this process (cgroup v2 cpu.max, v1 cfs quota / period), or None
+    if unlimited or unknown.  An affinity mask of 256 logical CPUs under a quota of 16 means 16: more threads than that only get
+    throttled (measured on the GPU box, round 4: 128 threads 81 Mrays/s, 16 threads 91)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = float(f.read())
+        return q / per if q > 0 else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(scene, width, height, budget_s=12.0):
     """Time the oracle (the CPU restatement of the reference path) on this host: whole frames of
     the SAME workload, repeated until ~budget_s of wall time, one thread per physical core of this process's affinity mask, plus one
@@ -114,8 +134,13 @@ def cpu_baseline(scene, width, height, budget_s=12.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi
     affinity, physical = host_cpus()
-    # one thread per physical core this process may run on; RPT_CPU_THREADS overrides
-    threads = max(1, int(os.environ.get("RPT_CPU_THREADS", physical or affinity or 1)))
+    quota = cpu_quota()
+    # one thread per physical core this process may run on AND is granted run time for (the cgroup's CPU quota caps
+    # it: the GPU box shows 256 logical CPUs and grants 16); RPT_CPU_THREADS overrides
+    granted = physical or affinity or 1
+    if quota:
+        granted = max(1, min(granted, int(quota + 0.5)))
+    threads = max(1, int(os.environ.get("RPT_CPU_THREADS", granted)))
     oracle_ffi.render(scene, width, min(height, 64), want_rgb=False, threads=threads)   # page in
     frames, t0 = 0, time.perf_counter()
     while True:
@@ -142,7 +167,7 @@ def cpu_baseline(scene, width, height, budget_s=12.0):
         pass
     return {
         "value": round(mt, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-        "affinity_cpus": affinity, "physical_cores": physical, "threads_used": threads,
+        "affinity_cpus": affinity, "physical_cores": physical, "cgroup_cpu_quota": quota, "threads_used": threads,
         "sample": f"{frames} whole frame(s) of the same workload ({width}x{height}), {el:.1f} s wall, {threads} threads; "
                   f"1-thread figure on the middle quarter band: {st:.3f} Mrays/s",
         "ms_per_frame": round(el / frames * 1e3, 2), "single_thread_mrays": round(st, 3), "cpu": cpu_model,
