@@ -99,7 +99,9 @@ if "--write" in sys.argv:
     text = re.sub(r"(### 6\.1 Table of record — library `)[0-9a-f]+(…`)", lambda m: m.group(1) + h16 + m.group(2), text)
     open(path, "w").write(text)
     path = os.path.join(ROOT, "profiles", "README.md")
-    text = open(path).read()
+    whole = open(path).read()
+    cut = whole.rindex("## Round ")            # only the current round's section is rewritten
+    keep, text = whole[:cut], whole[cut:]
     text = re.sub(r"(Library of record: `librpt_hip.so` sha256 `)[0-9a-f]+(…`)", lambda m: m.group(1) + h16 + m.group(2), text)
     d = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_bench_bunny_3840x2160.json")))
     r = d["roofline"]
@@ -111,5 +113,5 @@ if "--write" in sys.argv:
     rp = rocprof_blocking_ms("bunny_3840x2160")
     if rp:
         text = re.sub(r"(the cold first one included\) )[0-9.]+( µs average)", lambda m: m.group(1) + f"{rp * 1e3:.1f}" + m.group(2), text)
-    open(path, "w").write(text)
+    open(path, "w").write(keep + text)
     print("written: DESIGN.md sections 6.1 / 6.2, profiles/README.md")
