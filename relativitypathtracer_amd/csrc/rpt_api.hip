@@ -851,6 +851,7 @@ int rpt_create(rpt_ctx **out, int device_ordinal) {
     rpt_ctx *ctx = new (std::nothrow) rpt_ctx();
     if (!ctx) return RPT_ERR_NOMEM;
     ctx->device = device_ordinal;
+    (void)rpth::Workers::instance();       // the helper pool exists from the first context on, not from the first animated frame (rpt_workers.hpp: fork())
     {
         static std::atomic<int> created{0};
         ctx->serial = created.fetch_add(1);

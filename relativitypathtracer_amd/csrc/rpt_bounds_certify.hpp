@@ -70,8 +70,11 @@
 //    float hit, lies outside P: no pixel of the frame outside the claimed region can hit the object.                          q.e.d.
 //
 // What the proof does NOT cover is stated where it matters: it is a statement about the three intersectors as written in
-// rpt_kernels.hip.h (a change to their arithmetic needs section 2 redone), for frames of at most 4 : 1 and at most 2^20 pixels a side
-// (launch() falls back to the un-culled kernel otherwise), and for finite matrices below 1e15 in magnitude (no float overflow).
+// rpt_kernels.hip.h and compiled with IEEE division and square root and without contraction (a change to their arithmetic needs
+// section 2 redone; the opt-in relaxed-arithmetic build, variants 50 / 51 — not a parity path — runs the same culls with a 2.5-ulp
+// division inside budgets that were observed to be used to a fifth, which is an observation, not part of this proof), for frames of
+// at most 4 : 1 and at most 2^20 pixels a side (launch() falls back to the un-culled kernel otherwise), and for finite matrices below
+// 1e15 in magnitude (no float overflow).
 #pragma once
 #include <algorithm>
 #include <cmath>

@@ -12,7 +12,9 @@
 // The workers are never joined (the pool is leaked on purpose: a library has no safe moment to join threads at process exit).
 // fork(): the child has none of the parent's threads but inherits the pool's counters and, possibly, a mutex some worker held
 // at that instant.  A pthread_atfork child handler empties the pool (n_threads_ = 0, counters 0, no job): every parallel_for of
-// the child then takes the solo path and never touches m_ or callers_ again.
+// the child then takes the solo path and never touches m_ or callers_ again.  The pool is created in rpt_create (not lazily in
+// the first frame): a fork() that overlapped its construction would leave the child waiting on the initialisation guard of
+// instance() for a thread it does not have (tests/native/workers_stress.cpp found exactly that).
 #pragma once
 #include <atomic>
 #include <chrono>

@@ -3,6 +3,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <cerrno>
 #include <cstring>
 #include <sys/wait.h>
 #include <thread>
@@ -41,6 +42,9 @@ static int submit(int rounds, unsigned seed) {
 // may have held) said at that instant.  Its batches must still complete — on the calling thread alone (pthread_atfork child
 // handler in rpt_workers.hpp) — and it must report threads 0.
 static int fork_mode(int forks) {
+    // the pool exists before anything forks (the library creates it in rpt_create): a fork DURING its construction — a function-local
+    // static being initialised by another thread — would leave the child waiting for an initialiser that does not exist there
+    (void)rpth::Workers::instance().threads();
     std::atomic<bool> stop{false};
     std::thread busy([&] { while (!stop.load()) submit(50, 7u); });
     int bad = 0;
@@ -49,11 +53,18 @@ static int fork_mode(int forks) {
         const pid_t pid = fork();
         if (pid == 0) {
             alarm(20);                                            // a child that hangs dies of SIGALRM and is counted
-            const int b = submit(200, 100u + (unsigned)f) + (rpth::Workers::instance().threads() != 0);
-            _exit(b ? 1 : 0);
+            const int b = submit(200, 100u + (unsigned)f);
+            _exit(b ? 1 : (rpth::Workers::instance().threads() != 0 ? 2 : 0));
         }
         int status = 0;
-        if (pid < 0 || waitpid(pid, &status, 0) != pid || !WIFEXITED(status) || WEXITSTATUS(status) != 0) bad++;
+        pid_t w = -1;
+        if (pid > 0) do { w = waitpid(pid, &status, 0); } while (w < 0 && errno == EINTR);
+        if (pid < 0 || w != pid || !WIFEXITED(status) || WEXITSTATUS(status) != 0) {
+            bad++;
+            std::fprintf(stderr, "fork %d: pid %d waitpid %d errno %d exited %d code %d signalled %d signal %d\n", f, (int)pid, (int)w, errno,
+                         pid > 0 && w == pid ? WIFEXITED(status) : -1, pid > 0 && w == pid && WIFEXITED(status) ? WEXITSTATUS(status) : -1,
+                         pid > 0 && w == pid ? WIFSIGNALED(status) : -1, pid > 0 && w == pid && WIFSIGNALED(status) ? WTERMSIG(status) : -1);
+        }
     }
     stop.store(true);
     busy.join();
