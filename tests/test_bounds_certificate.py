@@ -201,3 +201,59 @@ def test_inputs_outside_the_error_model_prove_nothing():
     assert claims_nothing(proposed(o, -1, None))
     ok, st = certify(o, -1, None, (-0.1, -0.1, 0.1, 0.1, -FULL, FULL, -FULL, FULL))
     assert not ok and st[0] == 4, st
+
+
+def test_corrupted_object_records_never_yield_an_unsound_bound():
+    """Object records with damaged matrices — single bit flips, entries scaled by 1e+-20, rows swapped, InvM no longer the inverse of M,
+    a Lorentz matrix that is no boost — go through what rpt_set_objects runs (proposal + proof).  Whatever bound comes out is either
+    the full plane or contains every pixel the oracle hits with the SAME damaged record: the proof reads the matrices the kernel
+    reads and assumes nothing about where they came from."""
+    rng = np.random.default_rng(99)
+    lib = _ffi.hip()
+    W, H = 128, 72
+    u, v = _grid(W, H)
+    used = kept = 0
+    for trial in range(240):
+        name = ("shadows", "cubes", "arch", "soccer", "bunny")[trial % 5]
+        s = load_config(name)
+        objs = s.objects().copy()
+        i = int(rng.integers(0, min(len(objs), 8)))
+        field = ("M", "InvM", "Lorentz", "InvLorentz", "stationaryCam")[int(rng.integers(0, 5))]
+        raw = objs[field][i].reshape(-1).copy()
+        kind = int(rng.integers(0, 5))
+        k = int(rng.integers(0, raw.size))
+        if kind == 0:
+            bits = raw.view(np.uint32).copy()
+            bits[k] ^= np.uint32(1) << np.uint32(rng.integers(0, 32))
+            raw = bits.view(np.float32)
+        elif kind == 1:
+            raw[k] *= np.float32(10.0 ** rng.choice([-20, -6, -2, 2, 6, 20]))
+        elif kind == 2 and raw.size == 16:
+            m = raw.reshape(4, 4).copy()
+            a, b = rng.choice(4, size=2, replace=False)
+            m[[a, b]] = m[[b, a]]
+            raw = m.reshape(-1)
+        elif kind == 3:
+            raw[k] = np.float32(rng.normal(scale=3.0))
+        else:
+            raw[k] = -raw[k]
+        objs[field][i] = raw.reshape(objs[field][i].shape)
+        rec = objs[i:i + 1].copy()
+        root = _root(s, objs, i)
+        b = (C.c_float * 8)()
+        assert lib.rpt_object_screen_bounds(rec.ctypes.data, s.params["interval"], root, b) == 0       # (must return, whatever the record holds)
+        b = tuple(b)
+        used += 1
+        if claims_nothing(b):
+            continue
+        kept += 1
+        only = rec.copy()
+        only["light"] = 0
+        only["textureIndex"] = -1
+        only["flashPeriod"] = 0
+        only["color"] = (1.0, 0.5, 0.25, 0.0)
+        _, rgb, _ = oracle_ffi.render(s, W, H, objects=only)
+        hit = ~((rgb == tsb._background(s, W, H)).all(axis=2))          # (a NaN colour is a hit too: it is not the background)
+        bad = hit & ~tsb.inside_bounds(b, u, v)
+        assert not bad.any(), f"trial {trial} ({name} object {i}, {field}[{k}] kind {kind}): a proven bound {b} leaves out {int(bad.sum())} hit pixels"
+    assert used == 240 and kept > 40, (used, kept)
