@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--last", type=int, default=2000)
     ap.add_argument("--kinds", default="random,extreme,close")
+    ap.add_argument("--size", default="", help="WxH: every scene at this one size (e.g. 3840x2160: above 3 Mpx the default selection is kernel 41)")
     args = ap.parse_args()
     r = Renderer(0)
     sizes = [(320, 184), (256, 144), (200, 150), (640, 360), (360, 640), (1024, 256), (333, 77), (1280, 720)]     # landscape, portrait, 4 : 1, odd
@@ -82,7 +83,7 @@ def main():
                 s, text = build(kind, seed)
             except Exception as e:      # a generator may produce a scene the front end rejects
                 continue
-            W, H = sizes[seed % len(sizes)]
+            W, H = sizes[seed % len(sizes)] if not args.size else tuple(int(x) for x in args.size.split("x"))
             r.upload_scene(s)
             r.set_scene_params(s, W, H)
             r.set_output(None)
