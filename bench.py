@@ -304,6 +304,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        # one process per GPU: no helper threads for the screen bounds (four polling threads per rank beside the RCCL proxies buy
+        # nothing on a still scene; the pool reads this when the first context is created — INTEGRATION.md section 5)
+        os.environ.setdefault("RPT_HOST_THREADS", "0")
     n = args.gpus
     n = world                                        # the launcher's word: one rank per GPU
     if not torch.cuda.is_available():
