@@ -13,14 +13,17 @@
 //    pixel -> (fu, fv) floats, a point of the WINDOW  |fu| <= 2, |fv| <= 1/2  when the frame is at most 4 : 1 (launch() culls only
 //      then).  Real numbers from here on: whatever rounding produced them, they are SOME point of the window, and every point of the
 //      window outside the claimed region is covered by the proof.
-//    nd   = normalize((fu, fv, 1/2))          nd_j = d_j / |d| (1 + e), |e| <= 4u     (3-term dot 3u, sqrt 1.5u + u, divide u)
-//    d3_k = dot(Lorentz[k], (interval, nd))   4-term dot: error <= 4u sum_j |L_kj| |w_j|; with the input error of nd:
-//                                              |d3_k - (L w)_k| <= 8.1u sum_j |L_kj|            (|w_j| <= 1)
-//    dir  = transformDirection(InvM, d3)      3-term dot: |dir_i - (I L w)_i| <= 11.2u sum_k |I_ik| sum_j |L_kj|
-//    dirn = dir / length(dir)                 dirn_i = dir_i / |dir| (1 + e), |e| <= 4u: as a DIRECTION, dir_i (1 + e)
+//    nd   = normalize(normalize((fu, fv, 1/2)))   TWICE, as the reference does (createCamRay normalises, intersect_scene normalises again:
+//                                              opencl_kernel.cl:71, 387; rpt_kernels.hip.h: createCamRayDir, trace).  One normalisation:
+//                                              3-term dot 3u, sqrt 1.5u + u, divide u = 3.5u per component; the second one works on a
+//                                              vector whose own length is 1 +- 3.5u:   nd_j = d_j / |d| (1 + e), |e| <= 10.6u
+//    d3_k = dot(Lorentz[k], (interval, nd))   4-term dot: error <= 4.1u sum_j |L_kj| |w_j|; with the input error of nd:
+//                                              |d3_k - (L w)_k| <= 14.7u sum_j |L_kj|           (|w_j| <= 1)
+//    dir  = transformDirection(InvM, d3)      3-term dot: |dir_i - (I L w)_i| <= 17.8u sum_k |I_ik| sum_j |L_kj|
+//    dirn = dir / length(dir)                 dirn_i = dir_i / |dir| (1 + e), |e| <= 3.5u: as a DIRECTION, dir_i (1 + e)
 //    => the direction the intersector gets is, up to a positive factor,   A w + e,   A = InvM3 * Lorentz[1..3][0..3] (exact reals
-//       formed from the float matrices), w = (interval, nd), and   |e_i| <= ERR_i := 16u * sum_k |I_ik| sum_j |L_kj|   (11.2u + 4u of
-//       |dir_i| <= that same sum, rounded up; 16u = 2^-20).
+//       formed from the float matrices), w = (interval, nd), and   |e_i| <= ERR_i := 24u * sum_k |I_ik| sum_j |L_kj|   (17.8u + 3.5u of
+//       |dir_i| <= that same sum = 21.4u, rounded up).
 //    origin: DObj.ox/oy/oz — floats computed ONCE per frame on the host (build_dobjs) and read by the kernel: the certificate uses
 //       the very same floats, so the origin carries no error at all.
 //
@@ -151,7 +154,7 @@ inline bool setup(const rpt_object &ob, int interval, const float *root_bounds, 
             for (int j = 0; j < 4; j++) row += std::fabs(L[k][j]);
             e += std::fabs(I[i][k]) * row;
         }
-        p.err[i] = 16.0 * U24 * e * (1.0 + 1.0e-12);
+        p.err[i] = 24.0 * U24 * e * (1.0 + 1.0e-12);
         for (int j = 0; j < 4; j++) p.A[i][j] = I[i][0] * L[0][j] + I[i][1] * L[1][j] + I[i][2] * L[2][j];
     }
     // the homeomorphism and noise conditions: A3 = A[.][1..3], c = A3^-1 A[.][0] (interval = -1), r0 = (1 - |c|) / ||A3^-1||_F
@@ -399,9 +402,6 @@ inline bool segment_separable(Problem &p, double ua, double va, double ub, doubl
     double n[3];
     bool enclosed = false;
     for (int it = 0; it < GJK_STEPS; it++) {
-#ifdef RPT_CERT_COUNT
-        g_iters3++;
-#endif
         if (!closest_on_simplex(S, n)) { enclosed = true; break; }          // 0 inside the hull: not separable by a plane through o
         const double nn = dot3(n, n);
         if (!(nn > 1.0e-26) || !std::isfinite(nn)) break;
@@ -433,9 +433,6 @@ inline bool segment_separable(Problem &p, double ua, double va, double ub, doubl
     // shape are two convex sets of size ~ their angular size, and GJK on their Minkowski difference is well conditioned at any
     // scale.  A separating line m . y = tau gives the normal n = m1 e1 + m2 e2 - tau axis, which goes through the same check.
     {
-#ifdef RPT_CERT_COUNT
-        g_stage2++;
-#endif
         double ax[3] = {cv[0] * ics, cv[1] * ics, cv[2] * ics}, e1[3], e2[3];
         const double helper[3] = {std::fabs(ax[0]) < 0.6 ? 1.0 : 0.0, std::fabs(ax[0]) < 0.6 ? 0.0 : 1.0, 0.0};
         cross3(ax, helper, e1);
