@@ -195,3 +195,57 @@ def test_rays_the_kernel_skips_fail_the_float_root_test():
             assert not (skip[i] and passes), f"trial {trial} ray {i}: skipped, but the float root test passes (lo {lo}, hi {hi}, o {o[i]}, D {D[i]})"
     assert n_skip >= 0.8 * n_miss > 0, (n_skip, n_miss, n_total)
     print(f"{n_total} rays: {n_miss} fail the float root test, {n_skip} of them are skipped without the normalisation")
+
+
+def test_the_primary_direction_error_budget():
+    """rpt_bounds_certify.hpp section 1: the object-space direction the kernel hands its intersectors differs from the exact
+    A (interval, d / |d|) by at most ERR_i = 24u sum_k |InvM_ik| sum_j |Lorentz_kj| per component (as a direction).  The kernel's
+    chain — the camera direction normalised TWICE, the 4-term dot with Lorentz, the 3-term dot with InvM, the normalisation — is
+    restated here in numpy float32, operation for operation, on the objects of shipped and generated scenes at random points of the
+    window, and compared with the same chain in float64."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import verify_fuzz
+    rng = np.random.default_rng(21)
+    scenes = [load_config(n) for n in ("shadows", "cubes", "arch", "bunny")] + [verify_fuzz.build(k, 7000 + i)[0] for i, k in enumerate(("random", "extreme", "close", "walls", "ellipsoids", "meshwalls") * 6)]
+    worst = 0.0
+    checked = 0
+    for s in scenes:
+        interval = np.float32(s.params["interval"])
+        for o in s.objects()[:64]:
+            L = np.array(o["Lorentz"], dtype=np.float32).reshape(4, 4)
+            Iv = np.array(o["InvM"], dtype=np.float32).reshape(4, 4)
+            if not (np.isfinite(L).all() and np.isfinite(Iv).all()):
+                continue
+            n = 2000
+            fu = rng.uniform(-2, 2, size=n).astype(np.float32)
+            fv = rng.uniform(-0.5, 0.5, size=n).astype(np.float32)
+            d = np.stack([fu, fv, np.full(n, 0.5, np.float32)], axis=1)
+
+            def norm32(v):
+                dot = (v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2]
+                return (v / np.sqrt(dot, dtype=np.float32)[:, None]).astype(np.float32)
+            nd = norm32(norm32(d))
+            w = np.concatenate([np.full((n, 1), interval, np.float32), nd], axis=1)
+            d3 = np.stack([((L[k, 0] * w[:, 0] + L[k, 1] * w[:, 1]) + L[k, 2] * w[:, 2]) + L[k, 3] * w[:, 3] for k in (1, 2, 3)], axis=1).astype(np.float32)
+            dirf = np.stack([(Iv[i, 0] * d3[:, 0] + Iv[i, 1] * d3[:, 1]) + Iv[i, 2] * d3[:, 2] for i in range(3)], axis=1).astype(np.float32)
+            scale = np.sqrt((dirf[:, 0] * dirf[:, 0] + dirf[:, 1] * dirf[:, 1]) + dirf[:, 2] * dirf[:, 2], dtype=np.float32)
+            dirn = (dirf / scale[:, None]).astype(np.float32)
+            # exact (float64 on the float matrices)
+            d64 = d.astype(np.float64)
+            nd64 = d64 / np.linalg.norm(d64, axis=1, keepdims=True)
+            w64 = np.concatenate([np.full((n, 1), float(interval)), nd64], axis=1)
+            A = Iv[:3, :3].astype(np.float64) @ L[1:4, :].astype(np.float64)
+            D = w64 @ A.T
+            S = np.abs(Iv[:3, :3].astype(np.float64)) @ np.abs(L[1:4, :].astype(np.float64)).sum(axis=1)
+            if not (np.isfinite(D).all() and np.isfinite(dirn).all() and (S > 0).all()):
+                continue
+            # as a direction: dirn * (exact length of the float dir) against D
+            lenf = np.linalg.norm(dirf.astype(np.float64), axis=1, keepdims=True)
+            err = np.abs(dirn.astype(np.float64) * lenf - D) / S[None, :]
+            worst = max(worst, float(err.max()) / U)
+            checked += n
+    assert checked > 100000
+    assert worst <= 24.0, f"direction error {worst:.1f} u of the row sums: above the certificate's budget of 24"
+    print(f"{checked} directions: worst component error {worst:.2f} u x sum_k |InvM_ik| sum_j |L_kj| (budget 24)")
