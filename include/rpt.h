@@ -22,8 +22,9 @@
  * Not in the reference (it never reads back, has one device and no timing): rpt_read_framebuffer,
  * rpt_last_frame_ms, rpt_timed_frames, rpt_timing_*, the *_async/stream calls, rpt_create_multi, rpt_set_rows /
  * rpt_set_tile_pattern (pixel-row tiles for multi-GPU sharding), rpt_pack_/rpt_scatter_* (the exchange's two kernels),
- * rpt_build_octree (GPU counterpart of Mesh::GenerateOctree) and the test hooks rpt_probe, rpt_set_debug_rgb,
- * rpt_object_screen_rect.
+ * rpt_build_octree (GPU counterpart of Mesh::GenerateOctree) and the test hooks rpt_probe, rpt_probe_walk, rpt_probe_object,
+ * rpt_probe_division, rpt_set_debug_rgb, rpt_verify_frame, rpt_object_screen_rect / _bounds / _bounds_proposed,
+ * rpt_certify_screen_bounds and rpt_mesh_segment_cull_record (the last five are host code: no device needed).
  *
  * There is no CPU or OpenCL fallback: without a gfx950 device rpt_create fails.
  */

@@ -591,6 +591,29 @@ def test_bench_several_ranks_on_one_gpu_over_gloo(n, split, gather):
         assert out["config"]["sharding"].startswith("weighted")
 
 
+def test_shadow_ray_culls_on_the_shipped_meshes(renderer):
+    """Which shadow-ray culls a mesh gets is decided per object and frame on the host (csrc/rpt_api.hip: mesh_segment_cull_record) from
+    what can be PROVEN: every mesh gets the division-free root-miss test; the segment cull needs 16.2 K <= 0.25 (K = the mesh's
+    largest |e1| |e2|: the float triangle test's distance error near |det| = 1e-7 scales with it) and well-conditioned matrices.
+    bunny.obj keeps it (margin 0.46 % of the reach), pear.obj cannot (310 %).  A change that silently drops the bunny's cull, or
+    silently gives the pear one, shows here."""
+    for name, k_lo, k_hi, seg in (("bunny", 2.0e-4, 4.0e-4, True), ("shadows", 0.15, 0.25, False)):
+        scene = load_config(name)
+        _setup(renderer, scene, 320, 184)
+        objs = scene.objects()
+        mesh = int(np.flatnonzero(np.asarray(objs["type"]) == 2)[0])
+        rec = renderer.mesh_segment_cull_record(mesh)
+        assert (rec[0:3] > 0).all() and rec[9] == 1.0, (name, rec)                  # the ray test is on; the lists stay inside the root box
+        assert k_lo < rec[7] < k_hi, (name, rec[7])
+        if seg:
+            assert 0.0 < rec[4] < 0.01 and rec[3] > 0 and 1.0e-4 <= rec[6] < 1.0e-2 and 0 <= rec[5] < 1.0e-3, (name, rec)
+            assert abs(rec[4] - 1.001 * (16.2 * rec[7] + 3.2 * 2.0 ** -24)) < 1e-6
+        else:
+            assert rec[4] < 0, (name, rec)
+        analytic = int(np.flatnonzero(np.asarray(objs["type"]) != 2)[0])
+        assert renderer.mesh_segment_cull_record(analytic)[0] < 0                   # not a mesh: no record
+
+
 def test_bench_n_gt_1_line_carries_config_5():
     """With N > 1 the line also times BASELINE config 5 (bunny 7680x4320; here a smaller stand-in, two ranks on one GPU over gloo)
     in the three arrangements — the one shipped workload where sharding can pay."""
