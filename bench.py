@@ -603,7 +603,8 @@ def main():
         rf[device_key] = rf["frac"]
         rf["device_in_flight"] = {"achieved": rf["achieved"], "frac": rf["frac"], "launch_ms": rf["launch_ms"], "launches_overlapped": rf["launches_overlapped"],
                                   "kernel": kernel_name, "note": rf["regime"], "traffic": None}
-        rf["describes"] = f"device level, {frame.depth} frames in flight ({kernel_name})"
+        short = lambda label: label.split(" ")[0]          # noqa: E731  ("rpt_render_kernel_ballot_w5 (41; ...)" -> the kernel's name)
+        rf["describes"] = f"device level, {frame.depth} frames in flight ({short(kernel_name)})"
         if blocking_kernel_ms:
             a1 = alg / (blocking_kernel_ms * 1e-3) / 1e9
             # roofline.frac / achieved / launch_ms / kernel / traffic are the KERNEL-ALONE figures (the contract's "dominant kernel"
@@ -613,8 +614,8 @@ def main():
             rf.update({"achieved": round(a1, 2), "frac": round(a1 / HBM_PEAK_GBS, 5), "frac_kernel_alone": round(a1 / HBM_PEAK_GBS, 5),
                        "launch_ms": round(blocking_kernel_ms, 4), "launches_overlapped": 1.0,
                        "kernel": blocking_kernel_name,
-                       "describes": f"the kernel alone: {blocking_kernel_name}, one launch at a time (the blocking rpt_render); value / ms_per_step are "
-                                    f"the frames in flight, see roofline.device_in_flight ({kernel_name})",
+                       "describes": f"the kernel alone: {short(blocking_kernel_name)}, one launch at a time (the blocking rpt_render); value / ms_per_step are "
+                                    f"the {frame.depth} frames in flight, see roofline.device_in_flight ({short(kernel_name)})",
                        "regime": "one launch at a time, nothing overlapped (the blocking rpt_render): algorithmic bytes / the launch's own HIP-event duration"})
             rf["frac_blocking"] = rf["frac"]          # (round 2's name for the same number)
         else:
@@ -623,7 +624,6 @@ def main():
         # HBM traffic: rocprofv3 PMC passes of this command, quoted only when taken on THIS build, per kernel — the block of the
         # kernel each figure names
         if n == 1 and not force_dist and args.variant == 0:
-            short = lambda label: label.split(" ")[0]          # noqa: E731  ("rpt_render_kernel_ballot_w5 (41)" -> the name)
             traffic, source = measured_traffic(args.workload, W, H, short(rf["kernel"]))
             rf["traffic"] = traffic
             rf["traffic_source"] = (f"{source}, block {short(rf['kernel'])} (rocprofv3 --pmc of this command on this build of librpt_hip.so: recorded hash matches)"
