@@ -302,14 +302,12 @@ def _rest_frame_rays(scene, i, rng, n):
     org[onface, ax[onface]] = (c + h * rng.choice([-1.0, 1.0], size=(n, 1)))[onface, ax[onface]]   # exactly on a face plane
     target = c + rng.normal(size=(n, 3)) * h * rng.choice([0.3, 1.0, 1.0, 1.5], size=(n, 1))
     graz = rng.random(n) < 0.2
-    tang = unit(rng.normal(size=(n, 3)))
     target[graz] = (c + unit(rng.normal(size=(n, 3))) * h * (1.0 + rng.choice([-1e-6, 0.0, 1e-6, 1e-3], size=(n, 1))))[graz]   # sphere tangents / cube edges
     d = target - org
     along = rng.random(n) < 0.1
     d[along, ax[along]] = 0.0                                                               # parallel to a pair of faces
     d[rng.random(n) < 0.1] *= -1.0                                                          # pointing away
     d = d * np.exp(rng.uniform(-2, 2, size=(n, 1)))
-    _ = tang
     wo = org @ M[:3, :3].T + M[:3, 3]
     wd = d @ M[:3, :3].T
     rays = np.zeros((n, 8), dtype=np.float32)
@@ -378,7 +376,6 @@ def test_primary_ray_form_equals_the_general_form(kat):
     for obj in range(6):
         o = scene.objects()[obj]
         l4 = np.concatenate([np.full((n, 1), interval, np.float32), nd], axis=1)
-        boosted = oracle_ffi.object_rays(scene, 2, obj, np.concatenate([l4[:, 1:4], l4[:, 0:1]], axis=1))          # (unused: order check below)
         # transformPoint4D(Lorentz, (interval, nd)): the oracle's transform entry takes {x, y, z, w} = the 4-vector's four components in order
         boosted = oracle_ffi.object_rays(scene, 2, obj, l4)[:, 4:8]
         rays = np.concatenate([np.tile(np.asarray(o["stationaryCam"], dtype=np.float32), (n, 1)), boosted], axis=1)
