@@ -225,6 +225,46 @@ RPT_DEV int getOppositeBoxSide(const ExitPlan &p, f3 &uv) {
     return side;
 }
 
+// EXPERIMENT, not in the product build (RPT_PACKED_EXIT_FACES=1 turns it on in the throughput walk): the same plan with the three
+// candidate exit faces in ONE register, picked by a shift that depends on the step.  Written as above, the compiler hoists 3 - sx,
+// 5 - sy, 1 - sz out of the leaf loop as three registers; in kernel 41 (96 registers for five waves) two of them are spilled and
+// reloaded inside the loop.  The packed form removes those reloads (scratch 12 -> 8 B, the rest outside the loops) for one
+// instruction more per step.  Measured twice, A/B/A/B/A/B against the library of record: -1.5 / -1.7 / -0.7 % in flight in one
+// build, +0.2 / -0.7 / -1.6 % in the next: inside the run-to-run spread of the bench line, so the record stays as it is
+// (profiles/r04_exitplan_ab.txt).
+#ifndef RPT_PACKED_EXIT_FACES
+#define RPT_PACKED_EXIT_FACES 0
+#endif
+struct PackedExitPlan { f3 scaledDir, inv_dir, far; int sides; };
+
+RPT_DEV PackedExitPlan makePackedExitPlan(f3 scaledDir) {
+    PackedExitPlan p;
+    p.scaledDir = scaledDir;
+    p.inv_dir = mk3(1.0f / scaledDir.x, 1.0f / scaledDir.y, 1.0f / scaledDir.z);
+    const int sx = p.inv_dir.x < 0, sy = p.inv_dir.y < 0, sz = p.inv_dir.z < 0;
+    p.far = mk3((float)(1 - sx), (float)(1 - sy), (float)(1 - sz));
+    p.sides = (3 - sx) | ((5 - sy) << 8) | ((1 - sz) << 16);
+    return p;
+}
+
+RPT_DEV int getOppositeBoxSide(const PackedExitPlan &p, f3 &uv) {
+    const float dx = (p.far.x - uv.x) * p.inv_dir.x;
+    const float dy = (p.far.y - uv.y) * p.inv_dir.y;
+    const float dz = (p.far.z - uv.z) * p.inv_dir.z;
+    float t;
+    int shift;
+    if (dx < dy) {
+        if (dx < dz) { t = dx; shift = 0; } else { t = dz; shift = 16; }
+    } else {
+        if (dy < dz) { t = dy; shift = 8; } else { t = dz; shift = 16; }
+    }
+    uv = uv + p.scaledDir * t;
+    return (p.sides >> shift) & 0xff;
+}
+
+template <bool PACKED> struct ExitPlanOf { typedef ExitPlan type; static RPT_DEV ExitPlan make(f3 d) { return makeExitPlan(d); } };
+template <> struct ExitPlanOf<true> { typedef PackedExitPlan type; static RPT_DEV PackedExitPlan make(f3 d) { return makePackedExitPlan(d); } };
+
 // The same step for the common case 0 <= uv < 1.5 on every axis (+0 included, -0/NaN/negative excluded by
 // the unsigned compare on the bit patterns): there round(c) is (c >= 0.5), min(c, 1-eps) keeps that bit, and
 // 2*fmod(m, 0.5) is 2*(m - 0.5*bit) — every operation exact, so the results are those of the general form.
@@ -612,7 +652,7 @@ RPT_DEV bool octree_walk(const KernelArgs &a, const rpt_object &obj, int root, c
         if (!intersect_AABB(nmin, nmax, newRay, d, closeSide, farSide)) return false;
         uv = newRay.origin + newRay.dir * d.x;
     }
-    const ExitPlan plan = makeExitPlan(normalize(newRay.dir / (nmax - nmin)));
+    const typename ExitPlanOf<PACKED_COUNT && RPT_PACKED_EXIT_FACES>::type plan = ExitPlanOf<PACKED_COUNT && RPT_PACKED_EXIT_FACES>::make(normalize(newRay.dir / (nmax - nmin)));
     bool didHit = false;
     int hitTri = 0;
     TriRec first;
