@@ -186,11 +186,11 @@ def library_sha256():
         return None
 
 
-def measured_traffic(workload, width, height, kernel=None):
-    """HBM bytes per launch of `kernel` (its full name, e.g. rpt_render_kernel_ballot_first_w5) from a committed rocprofv3 PMC
-    summary (tools/profile.sh + tools/pmc_summary.py: separate --pmc passes, FETCH_SIZE doubled on gfx950, WRITE_SIZE as is; one
-    block per kernel) — ONLY if that summary was taken on this very build of librpt_hip.so (recorded hash == running hash);
-    otherwise None: counters cannot be collected from inside this process, and a number from another build would be stale."""
+def pmc_block(workload, width, height, kernel=None):
+    """The block of `kernel` (its full name, e.g. rpt_render_kernel_ballot_first_w5) in a committed rocprofv3 PMC summary
+    (tools/profile.sh + tools/pmc_summary.py: separate --pmc passes; one block per kernel) — ONLY if that summary was taken on this
+    very build of librpt_hip.so (recorded hash == running hash); otherwise None: counters cannot be collected from inside this
+    process, and a number from another build would be stale."""
     import glob
     mine = library_sha256()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_{width}x{height}_pmc_summary.json")), reverse=True):
@@ -203,11 +203,38 @@ def measured_traffic(workload, width, height, kernel=None):
                 blk = d["kernels"].get(kernel)
                 if blk is None:
                     continue
-                return int(sum(v for k, v in blk["derived"].items() if k.startswith("hbm_"))), os.path.relpath(path, ROOT)
-            return int(sum(v for k, v in d["derived"].items() if k.startswith("hbm_"))), os.path.relpath(path, ROOT)      # (rounds 1-3: kernels blended)
+                return blk, os.path.relpath(path, ROOT)
+            return d, os.path.relpath(path, ROOT)      # (rounds 1-3: kernels blended)
         except Exception:
             continue
     return None, None
+
+
+def measured_traffic(workload, width, height, kernel=None):
+    """HBM bytes per launch of `kernel` from that block: FETCH_SIZE doubled on gfx950, WRITE_SIZE as is."""
+    blk, source = pmc_block(workload, width, height, kernel)
+    if blk is None:
+        return None, None
+    return int(sum(v for k, v in blk["derived"].items() if k.startswith("hbm_"))), source
+
+
+# The other roof of this path.  The kernels are compute: a wave64 vector instruction occupies its SIMD-32 for 2 cycles
+# (MI355X_MICROARCH.md: 4 SIMDs per CU, 256 CUs, 2.4 GHz; 157.3 TFLOP/s of fp32 = that rate x 64 lanes x 2 for an FMA).
+VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2.0
+
+
+def measured_valu(workload, width, height, kernel, seconds_per_launch):
+    """Vector-ALU issue fraction of `kernel`: SQ_INSTS_VALU per launch (same PMC summary, same hash rule as the traffic) over
+    what the chip's 1 024 SIMDs can issue in `seconds_per_launch` — for launches that overlap, the interval between finished
+    frames.  lanes_active: of 64, the mean over the kernel's vector instructions (divergence: idle lanes issue all the same)."""
+    blk, source = pmc_block(workload, width, height, kernel)
+    n = blk and blk.get("SQ_INSTS_VALU", {}).get("mean")
+    if not n or not seconds_per_launch:
+        return None
+    lanes = blk.get("SQ_THREAD_CYCLES_VALU", {}).get("mean")
+    return {"wave_instructions_per_launch": int(n), "peak_wave_instructions_per_s": VALU_PEAK_WAVE_INSTR_PER_S,
+            "frac": round(n / (VALU_PEAK_WAVE_INSTR_PER_S * seconds_per_launch), 4),
+            "lanes_active_of_64": round(lanes / n, 1) if lanes else None, "kernel": kernel, "source": source}
 
 
 def spread(values):
@@ -629,6 +656,10 @@ def main():
             rf["traffic_source"] = (f"{source}, block {short(rf['kernel'])} (rocprofv3 --pmc of this command on this build of librpt_hip.so: recorded hash matches)"
                                     if source else "no committed PMC summary was taken on this build of librpt_hip.so")
             rf["device_in_flight"]["traffic"], _ = measured_traffic(args.workload, W, H, short(kernel_name))
+            # beside the contract's HBM figure: how much of the vector ALUs' issue rate the same launches use (the kernel alone over its
+            # own duration; the frames in flight over the interval between finished frames) — null without counters of this build
+            rf["valu"] = measured_valu(args.workload, W, H, short(rf["kernel"]), rf["launch_ms"] * 1e-3)
+            rf["device_in_flight"]["valu"] = measured_valu(args.workload, W, H, short(kernel_name), ms_per_step * 1e-3)
         if n > 1 or force_dist:
             out["comm"] = {"backend": td.get_backend(), "world_size": n, "ranks_in_group": td.get_world_size(),
                            "exchange": "ncclGather through ctypes (relativitypathtracer_amd/rccl.py), one per " + (f"{frame.group} frames" if frame.group > 1 else "frame") if comm is not None

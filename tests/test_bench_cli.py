@@ -68,3 +68,47 @@ def test_bare_single_gpu_line():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) < 0.02 * r["achieved"]
     assert out["ms_per_frame_blocking"] > 0 and out["frame_ms_blocking"]["median"] > 0 and out["launch_ms_in_flight"]["frames"] == 10
     assert "traffic" in r       # null unless a PMC summary of this very build is committed
+
+
+# ---- figures quoted from committed counter summaries --------------------------------------------------------------
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_counter_figures_are_quoted_only_for_the_build_they_were_taken_on(monkeypatch):
+    """roofline.traffic / roofline.valu come from profiles/*_pmc_summary.json, per kernel, and only when the summary's recorded
+    library hash is the running library's: a number from another build is stale and the line then says null."""
+    import json
+    bench = _load_bench()
+    summary = json.load(open(os.path.join(ROOT, "profiles", "r04_bunny_3840x2160_pmc_summary.json")))
+    recorded = summary["build"]["librpt_hip_sha256"]
+    k43, k41 = "rpt_render_kernel_ballot_first_w5", "rpt_render_kernel_ballot_w5"
+
+    monkeypatch.setattr(bench, "library_sha256", lambda: recorded)
+    t43, src = bench.measured_traffic("bunny", 3840, 2160, k43)
+    t41, _ = bench.measured_traffic("bunny", 3840, 2160, k41)
+    assert src == os.path.join("profiles", "r04_bunny_3840x2160_pmc_summary.json")
+    d43, d41 = summary["kernels"][k43]["derived"], summary["kernels"][k41]["derived"]
+    assert t43 == int(sum(v for k, v in d43.items() if k.startswith("hbm_"))) and t41 == int(sum(v for k, v in d41.items() if k.startswith("hbm_")))
+    assert t43 != t41                                              # one block per kernel, not a blend
+    assert 3840 * 2160 * 16 <= t41 < 1.5 * 3840 * 2160 * 16         # the frame is written once and little else moves
+
+    v = bench.measured_valu("bunny", 3840, 2160, k41, 0.1e-3)
+    n = summary["kernels"][k41]["SQ_INSTS_VALU"]["mean"]
+    assert v["wave_instructions_per_launch"] == int(n) and v["kernel"] == k41
+    assert v["peak_wave_instructions_per_s"] == 256 * 4 * 2.4e9 / 2          # a wave64 instruction holds its SIMD-32 for two cycles
+    assert abs(v["frac"] - n / (v["peak_wave_instructions_per_s"] * 0.1e-3)) < 1e-4
+    assert 1.0 <= v["lanes_active_of_64"] <= 65.0
+    assert bench.measured_valu("bunny", 3840, 2160, k41, None) is None
+    assert bench.measured_traffic("bunny", 3840, 2160, "rpt_render_kernel_nonexistent") == (None, None)
+
+    monkeypatch.setattr(bench, "library_sha256", lambda: "0" * 64)          # another build: nothing is quoted
+    assert bench.measured_traffic("bunny", 3840, 2160, k43) == (None, None)
+    assert bench.measured_valu("bunny", 3840, 2160, k43, 0.1e-3) is None
+    monkeypatch.setattr(bench, "library_sha256", lambda: None)              # no library at all
+    assert bench.measured_traffic("bunny", 3840, 2160, k43) == (None, None)

@@ -73,7 +73,10 @@ def main(src, dst, command=None):
             "hbm_read_bytes_per_launch (FETCH_SIZE KB x1024 x2 gfx950 correction)": mean("FETCH_SIZE") * 1024 * 2,
             "hbm_write_bytes_per_launch (WRITE_SIZE KB x1024)": mean("WRITE_SIZE") * 1024,
             "l2_hit_rate": hit / (hit + miss) if hit + miss else None,
-            "lanes_active_per_valu_instruction": (mean("SQ_THREAD_CYCLES_VALU") / mean("SQ_ACTIVE_INST_VALU") / 4.0) if mean("SQ_ACTIVE_INST_VALU") else None,
+            # (rounds 2-4 divided by SQ_ACTIVE_INST_VALU and by 4 here and recorded a quarter of the figure — the tables in DESIGN.md
+            # always used THREAD_CYCLES / INSTS, "of 64"; the committed r04 summaries were corrected in place by tools/fix_r04_lanes.py)
+            "lanes_active_per_valu_instruction": (mean("SQ_THREAD_CYCLES_VALU") / mean("SQ_INSTS_VALU")) if mean("SQ_INSTS_VALU") else None,
+            "valu_wave_instructions_per_launch": mean("SQ_INSTS_VALU") or None,
             "wave_life_waiting_share": (mean("SQ_WAIT_ANY") / mean("SQ_WAVE_CYCLES")) if mean("SQ_WAVE_CYCLES") else None,
         }
         kernels[key] = blk
